@@ -1,0 +1,256 @@
+/*
+ * mrt.h -- C-ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * The library (libmrt_hip.so) replaces ONE path of the Mafo369/Raytracer CPU renderer: what a
+ * sample does after camera-ray generation -- kd-tree traversal, ray/primitive intersection and
+ * the Cook-Torrance / light-sampling / MIS shading loop.  The reference reaches that path through
+ * per-ray C++ calls; a GPU needs batches, so every entry point below takes a whole batch and the
+ * comment on it names the reference interface it stands in for (paths relative to the
+ * reference's src/ directory).
+ *
+ * Conventions
+ *   - plain C types only; every function returns mrt_status (0 = ok) and never throws;
+ *     mrt_last_error() returns a per-thread message for the last failing call;
+ *   - all arrays in mrt_scene_desc are HOST memory, read during mrt_scene_create and not
+ *     retained (the library keeps its own device copy in its own layout);
+ *   - ray / hit / image buffers may be host or device memory, selected by MRT_BUF_DEVICE;
+ *   - one mrt_scene belongs to one HIP device; calls on one handle must be serialised by the
+ *     caller, calls on different handles may run concurrently;
+ *   - all arithmetic is IEEE fp32, unfused, in the reference's evaluation order, so that hit
+ *     primitive ids are bit-identical to the reference's intersectKdTree.
+ */
+#ifndef MRT_H
+#define MRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t mrt_status;
+enum {
+    MRT_OK              = 0,
+    MRT_ERR_INVALID     = 1, /* bad argument / inconsistent scene description */
+    MRT_ERR_DEVICE      = 2, /* HIP runtime error (no device, launch failure ...) */
+    MRT_ERR_NOMEM       = 3, /* device or host allocation failed */
+    MRT_ERR_UNSUPPORTED = 4
+};
+
+/* Object kinds: the values of the reference's Etype (geometry.h:5). */
+enum { MRT_SPHERE = 1, MRT_PLANE = 2, MRT_TRIANGLE = 3 };
+
+/* MatType (Material.h:14). */
+enum { MRT_MAT_DIFFUSE = 0, MRT_MAT_SPECULAR = 1, MRT_MAT_TRANSPARENT = 2 };
+
+/* Transform (defines.h:67-148): m_transform, m_invTransform as glm column-major mat3
+ * (element [3*col+row]) and m_translation. */
+typedef struct mrt_transform {
+    float m[9];
+    float inv[9];
+    float t[3];
+} mrt_transform;
+
+/* The Cook-Torrance fields of Material (Material.h:102-140) read by eval()/sample(). */
+typedef struct mrt_material {
+    float albedo[3];
+    float emission[3];
+    float ior;
+    float roughness;
+    float metalness;
+    int32_t type;    /* MRT_MAT_* */
+    int32_t texture; /* index into textures, -1 = none (m_texture == nullptr) */
+} mrt_material;
+
+/* texture (textures.hpp:13-125): image_texture or checker_texture of two solid colours. */
+enum { MRT_TEX_IMAGE = 0, MRT_TEX_CHECKER = 1 };
+typedef struct mrt_texture {
+    int32_t kind;
+    uint32_t width, height; /* image: texel grid */
+    uint64_t texel_offset;  /* image: first float of this image in mrt_scene_desc.texels (RGB) */
+    float even[3], odd[3];  /* checker colours */
+    mrt_transform xf;       /* texture::m_transform */
+} mrt_texture;
+
+/* One flattened kd-tree node, 8 bytes (replaces KdTreeNode, kdtree.h:11-21).
+ *   inner: w0 = bit pattern of the float split position
+ *          w1 = axis (bits 0-1, 0..2) | index of the LEFT child << 2 ; right child = left + 1
+ *   leaf : w0 = offset of the first reference in mrt_scene_desc.refs
+ *          w1 = 3 | number of references << 2
+ * Node 0 is the root.  Leaf references keep the order of KdTreeNode::objects. */
+typedef struct mrt_kdnode {
+    uint32_t w0;
+    uint32_t w1;
+} mrt_kdnode;
+
+/* Light (Light.h:167-254).  A ShapeLight owns a private copy of its emitter shape
+ * (example_scenes.cpp:119-129, 1501-1502), described inline here. */
+enum { MRT_LIGHT_SHAPE = 0, MRT_LIGHT_IBL = 1 };
+typedef struct mrt_light {
+    int32_t kind;       /* MRT_LIGHT_* */
+    float color[3];     /* Light::m_color */
+    int32_t shape_kind; /* MRT_TRIANGLE or MRT_SPHERE (shape lights) */
+    uint32_t transform; /* index into transforms */
+    float tri_p[9];     /* geom.triangle.p1..p3 */
+    float tri_n[9];     /* geom.triangle.n1..n3 */
+    float sphere[4];    /* geom.sphere.center, geom.sphere.radius */
+} mrt_light;
+
+/* SimpleCamera (Camera.h:24-49) after its constructor ran. */
+typedef struct mrt_camera {
+    float pos[3];
+    float near_top_left[3];
+    float dx_pixel[3];
+    float dy_pixel[3];
+    float x_dir[3];
+    float up[3];
+    float lens_radius;
+} mrt_camera;
+
+/* Flattened Scene + KdTree (scene.h:19-43, kdtree.h:23-32).  Object i of the reference's
+ * Scene::objects is entry i of every obj_* array; primitive ids reported by the library are
+ * these indices. */
+typedef struct mrt_scene_desc {
+    uint32_t struct_size; /* sizeof(mrt_scene_desc), for versioning */
+
+    uint32_t n_objects;
+    const uint8_t* obj_kind;       /* [n] MRT_SPHERE / MRT_PLANE / MRT_TRIANGLE */
+    const uint32_t* obj_material;  /* [n] Object::m_MaterialIndex */
+    const uint32_t* obj_transform; /* [n] index into transforms */
+    const float* tri_p;            /* [n][9] p1 p2 p3 (object space); unused rows ignored */
+    const float* tri_n;            /* [n][9] n1 n2 n3 */
+    const float* tri_uv;           /* [n][6] tex[0] tex[1] tex[2] */
+    const float* sphere;           /* [n][4] geom.sphere.center, radius */
+
+    uint32_t n_transforms;
+    const mrt_transform* transforms;
+
+    uint32_t n_materials;
+    const mrt_material* materials;
+
+    uint32_t n_textures;
+    const mrt_texture* textures;
+    uint64_t n_texels; /* floats */
+    const float* texels;
+
+    /* KdTree */
+    uint32_t n_nodes; /* 0 when the scene has no in-tree object */
+    const mrt_kdnode* nodes;
+    uint32_t n_refs;
+    const uint32_t* refs;
+    float root_min[3], root_max[3]; /* root->min / root->max (already padded by 1) */
+    uint32_t n_out_of_tree;
+    const uint32_t* out_of_tree; /* KdTree::outOfTree (planes) */
+
+    /* Scene::lights, Scene::envLights */
+    uint32_t n_lights;
+    const mrt_light* lights;
+    int32_t env_light; /* index in lights of the IBL that is also in envLights, -1 = none */
+    uint32_t env_width, env_height;
+    const float* env_rgb; /* [h][w][3] IBL::m_pixels */
+    float env_inv[9];     /* IBL::m_transform.getInvTransform() */
+
+    mrt_camera camera;
+    uint32_t has_camera;
+} mrt_scene_desc;
+
+typedef struct mrt_scene mrt_scene; /* opaque, one per device */
+
+/* Buffer placement flag for rays / hits / images. */
+enum { MRT_BUF_HOST = 0, MRT_BUF_DEVICE = 1 };
+
+/* Ray batch, struct of arrays.  tmin/tmax as in Ray (ray.h:5-30). */
+typedef struct mrt_rays {
+    const float* ox;
+    const float* oy;
+    const float* oz;
+    const float* dx;
+    const float* dy;
+    const float* dz;
+    const float* tmin;
+    const float* tmax;
+} mrt_rays;
+
+/* Hit batch.  prim = object index or -1; t = Ray::tmax after the call; u,v = barycentric
+ * weights of p2 and p3 for triangles (triangle.cpp:24-31), 0 otherwise. */
+typedef struct mrt_hits {
+    int32_t* prim;
+    float* t;
+    float* u;
+    float* v;
+} mrt_hits;
+
+enum {
+    MRT_CLOSEST_HIT = 0, /* Ray::shadow == false */
+    MRT_ANY_HIT     = 1  /* Ray::shadow == true: first non-emissive occluder (kdtree.cpp:532-538) */
+};
+
+/* Per-batch traversal statistics (filled when non-NULL): totals over the batch of inner nodes
+ * visited, leaves visited, leaf references read and primitive tests executed. */
+typedef struct mrt_trace_stats {
+    uint64_t inner, leaves, refs, prim_tests;
+} mrt_trace_stats;
+
+typedef struct mrt_render_params {
+    uint32_t width, height;
+    uint32_t spp_x, spp_y;                 /* StratifiedSampler(spp_x, spp_y, true, 8) */
+    uint32_t sample_begin, sample_end;     /* sample indices rendered by this call */
+    uint32_t max_depth;                    /* Pathtracer(maxDepth, ...) */
+    uint32_t seed;                         /* replaces time(NULL) of CPURenderer.cpp:42 */
+    uint32_t row_begin, row_end;           /* scanlines rendered by this call (tile split) */
+    uint32_t paths_per_pass;               /* 0 = library default */
+} mrt_render_params;
+
+typedef struct mrt_render_stats {
+    uint64_t rays_closest; /* intersectKdTree-equivalent closest-hit queries */
+    uint64_t rays_any;     /* shadow queries */
+    uint64_t paths;        /* camera samples */
+    double extend_ms, shade_ms, connect_ms, generate_ms; /* device time per kernel class */
+} mrt_render_stats;
+
+/* initKdTree + the Scene the reference hands to its integrator (kdtree.h:35, scene.h:19-43),
+ * uploaded to `device` in the library's own layout. */
+mrt_status mrt_scene_create( const mrt_scene_desc* desc, int device, mrt_scene** out );
+void mrt_scene_destroy( mrt_scene* scene );
+
+/* Batched bool intersectKdTree(Scene*, KdTree*, Ray*, Intersection*) (kdtree.h:34,
+ * kdtree.cpp:555-613).  flags: MRT_CLOSEST_HIT or MRT_ANY_HIT; placement: MRT_BUF_*.
+ * stream: a hipStream_t (NULL = the default stream); the call returns after the work has
+ * completed when the buffers are host memory, and is asynchronous on `stream` when they are
+ * device memory. */
+mrt_status mrt_intersect( mrt_scene* scene,
+                          uint64_t n,
+                          const mrt_rays* rays,
+                          const mrt_hits* hits,
+                          uint32_t flags,
+                          uint32_t placement,
+                          void* stream,
+                          mrt_trace_stats* stats );
+
+/* The per-sample body of CPURenderer::run (rendering/CPURenderer.cpp:46-62): camera sample,
+ * SimpleCamera::get_ray, Pathtracer::trace_ray (integrator.cpp:128-211), summed per pixel.
+ * rgb_sum is [height][width][3] floats of LINEAR radiance SUMS (not averaged, not gamma
+ * encoded); the call ADDS to it, so sample ranges and passes accumulate. */
+mrt_status mrt_render( mrt_scene* scene,
+                       const mrt_render_params* params,
+                       float* rgb_sum,
+                       uint32_t placement,
+                       void* stream,
+                       mrt_render_stats* stats );
+
+/* Average + gamma of CPURenderer.cpp:64-69 on a sum buffer: out = powf(sum / spp, 1.0f / 2.2). */
+mrt_status mrt_resolve( mrt_scene* scene,
+                        uint64_t n_pixels,
+                        const float* rgb_sum,
+                        uint32_t spp,
+                        float* rgb_out,
+                        uint32_t placement,
+                        void* stream );
+
+const char* mrt_last_error( void );
+int32_t mrt_version( void );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRT_H */

@@ -1,0 +1,307 @@
+// mrt_host.hpp -- C++ host side of the MI355X path-tracing backend.
+//
+// It mirrors the part of the Mafo369/Raytracer C++ API that sits directly above the hot path
+// (same names, argument meaning and ownership; the citations are paths relative to the reference's
+// src/), so that code written against the reference -- scene set-up, initKdTree, an ImageRenderer --
+// can switch to the GPU backend:
+//
+//   Scene* scene = initScene();  ... CreateMaterial / addObjectsFromFile / setSimpleCamera ...
+//   HIPRenderer r;  r.init(name, {w, h}, scene);  r.run();  r.destroy();
+//
+// The SAH kd-tree is still built on the CPU (initKdTree); flatten() turns Scene + KdTree into the
+// mrt_scene_desc that the C-ABI (mrt.h) uploads.  Nothing here touches the GPU except HIPRenderer
+// and intersectKdTree, which call the C-ABI.
+#pragma once
+
+#include "mrt.h"
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace mrt {
+
+struct vec2 {
+    float x = 0, y = 0;
+};
+struct vec3 {
+    float x = 0, y = 0, z = 0;
+    vec3() {}
+    vec3( float a, float b, float c ) : x( a ), y( b ), z( c ) {}
+    explicit vec3( float a ) : x( a ), y( a ), z( a ) {}
+    float operator[]( int i ) const { return i == 0 ? x : ( i == 1 ? y : z ); }
+    float& operator[]( int i ) { return i == 0 ? x : ( i == 1 ? y : z ); }
+};
+typedef vec3 point3;
+typedef vec2 point2;
+typedef vec3 color3;
+struct mat3 { // column-major, c[col][row]
+    float c[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+};
+
+// Transform (defines.h:67-148): same operations, same arithmetic.
+class Transform
+{
+  public:
+    mat3 const& getTransform() const { return m_transform; }
+    vec3 const& getTranslation() const { return m_translation; }
+    mat3 const& getInvTransform() const { return m_invTransform; }
+    vec3 transformTo( vec3 const& p ) const;
+    vec3 transformFrom( vec3 const& p ) const;
+    vec3 vectorTransformFrom( vec3 const& dir ) const;
+    void translate( vec3 const& p );
+    void rotate( vec3 const& axis, float degrees );
+    void scale( float sx, float sy, float sz );
+    void transform( mat3 const& m );
+    bool isIdentity() const;
+    bool operator==( Transform const& o ) const;
+
+  private:
+    mat3 m_transform, m_invTransform;
+    vec3 m_translation;
+};
+
+enum MatType { DIFFUSE = 0, SPECULAR = 1, TRANSPARENT = 2 }; // Material.h:14
+enum class MaterialModel { COOK_TORRANCE = 0, BLINN = 1 };   // Material.h:100
+
+// texture hierarchy of textures.hpp reduced to the two kinds the path tracer can reach.
+struct texture {
+    int kind = MRT_TEX_IMAGE;
+    uint32_t width = 0, height = 0;
+    std::vector<float> texels; // RGB, row-major, 8-bit / 255 (image.cpp:13-40)
+    color3 even, odd;
+    Transform m_transform;
+};
+texture* image_texture( const char* png_or_ppm_filename );
+texture* checker_texture( color3 c1, color3 c2 );
+
+// Material (Material.h:102-165), Cook-Torrance members.
+class Material
+{
+  public:
+    Material( size_t UID, MaterialModel matModel, MatType matType );
+    MaterialModel m_MatModel;
+    texture* m_texture = nullptr;
+    color3 m_emission  = color3( 0, 0, 0 );
+    color3 m_albedo    = color3( 0, 0, 0 );
+    float m_IOR        = 1.f;
+    float m_roughness  = 0.1f;
+    float m_metalness  = 0.001f;
+    MatType m_MatType  = DIFFUSE;
+    size_t m_UID;
+};
+
+enum Etype { SPHERE = 1, PLANE, TRIANGLE, CUBE }; // geometry.h:5
+
+struct Geometry { // geometry.h:7-42
+    Etype type = TRIANGLE;
+    struct {
+        vec3 center;
+        float radius = 0;
+    } sphere;
+    struct {
+        vec3 p1, p2, p3, n1, n2, n3, normal;
+        vec2 tex[3];
+    } triangle;
+};
+
+// Object (Object.h:10-26).  Intersection and sampling run on the GPU; the host object only
+// carries the data.
+class Object
+{
+  public:
+    Object( size_t materialIndex, Transform transform ) : transform( transform ), m_MaterialIndex( materialIndex ) {}
+    Transform transform;
+    Geometry geom;
+    size_t m_MaterialIndex;
+};
+class Plane : public Object // shapes/plane.h
+{
+  public:
+    Plane( size_t materialIndex, Transform transform ) : Object( materialIndex, transform ) { geom.type = PLANE; }
+};
+
+// Light (Light.h:9-44) -> the two kinds a Pathtracer scene uses.
+class Light
+{
+  public:
+    virtual ~Light() = default;
+    color3 m_color;
+};
+class ShapeLight : public Light // Light.h:167-198; owns a private copy of its shape
+{
+  public:
+    ShapeLight( vec3 position, color3 color, Object* obj ) : m_shape( obj ) { m_color = color; }
+    ~ShapeLight() { delete m_shape; }
+    Object* m_shape;
+};
+class IBL : public Light // Light.h:200-254; loads a Radiance .hdr file
+{
+  public:
+    explicit IBL( const std::string& filename );
+    IBL( int width, int height, std::vector<float> rgb ); // pixels supplied by the caller
+    Transform m_transform;
+    int m_width = 0, m_height = 0;
+    std::vector<float> m_pixels;
+};
+
+class Camera // Camera.h:12-22
+{
+  public:
+    virtual ~Camera() = default;
+    float imgWidth = 0, imgHeight = 0;
+};
+class SimpleCamera : public Camera // Camera.h:24-49, Camera.cpp:5-35
+{
+  public:
+    SimpleCamera( point3 lookfrom, point3 lookat, vec3 vup, float vfov, float aspect_ratio, int width, int height, float lensRadius, float focalDistance );
+    vec3 pos, dir, up, left, nearPlaneTopLeft, dXPixel, dYPixel, xDir;
+    float fov, aspect, l, h, w, m_lensRadius, m_focalDistance;
+};
+
+typedef std::vector<Object*> Objects;
+typedef std::vector<Light*> Lights;
+
+class Scene // scene.h:19-43
+{
+  public:
+    ~Scene();
+    Lights lights;
+    Lights envLights;
+    Objects objects;
+    std::vector<Material> m_Materials;
+    Camera* cam = nullptr;
+    std::vector<texture*> owned_textures;
+    Material& CreateMaterial( MaterialModel materialModel, MatType materialType = DIFFUSE ) {
+        size_t id = m_Materials.size();
+        return m_Materials.emplace_back( id, materialModel, materialType );
+    }
+    Material& GetMaterial( int index ) { return m_Materials[index]; }
+};
+
+// scene.h:45-118
+Scene* initScene();
+void freeScene( Scene* scene );
+Object* initSphere( int materialIndex, Transform transform );
+Object* initTriangle( vec3 p1, vec3 p2, vec3 p3, vec3 n, vec2 t[3], Transform transform, int materialIndex );
+Object* initSmoothTriangle( vec3 p1, vec3 p2, vec3 p3, vec3 n, vec2 t[3], vec3 n1, vec3 n2, vec3 n3, Transform transform, int materialIndex );
+void addObject( Scene* scene, Object* obj );
+void addLight( Scene* scene, Light* light );
+void setSimpleCamera( Scene* scene, point3 position, vec3 at, vec3 up, float fov, float w, float h, float radius, float distFocus );
+// example_scenes.cpp:22-153.  default_mat is taken BY INDEX semantics: the reference keeps a
+// reference into Scene::m_Materials across CreateMaterial calls; here the id is read up front.
+void addObjectsFromFile( const char* filename, Scene* scene, Material& default_mat, Transform& transform );
+// Same, with every vertex multiplied by `prescale` first and `subdivisions` rounds of 1 -> 4
+// midpoint subdivision (for meshes whose triangles would fail the |det| < 1e-4 test, and for
+// building large stress meshes from a small file).
+void addObjectsFromFileEx( const char* filename, Scene* scene, size_t default_mat, Transform& transform, float prescale, int subdivisions );
+
+// kdtree.h:11-35
+struct KdTreeNode {
+    bool leaf = false;
+    int axis  = 0;
+    float split = 0;
+    int depth = 0;
+    std::vector<int> objects;
+    KdTreeNode* left  = nullptr;
+    KdTreeNode* right = nullptr;
+    vec3 min, max;
+    ~KdTreeNode();
+};
+class KdTree
+{
+  public:
+    ~KdTree();
+    int depthLimit  = 80;
+    size_t objLimit = 0;
+    KdTreeNode* root = nullptr;
+    std::vector<int> outOfTree;
+    std::vector<int> inTree;
+    mrt_scene* device_scene = nullptr; // created on first intersectKdTree / by HIPRenderer
+    struct FlatScene* flat  = nullptr;
+};
+KdTree* initKdTree( Scene* scene );                 // kdtree.cpp:54-158, multi-threaded, same tree
+KdTree* initKdTree( Scene* scene, int n_threads );
+
+// Ray / Intersection as far as intersectKdTree's callers use them (ray.h:5-30, intersection.h:6-43).
+class Ray
+{
+  public:
+    Ray() {}
+    Ray( const point3& o, const vec3& d, float tmin_ = 0, float tmax_ = 100000, int depth_ = 0 ) : orig( o ), dir( d ), tmax( tmax_ ), tmin( tmin_ ), depth( depth_ ) {}
+    point3 orig;
+    vec3 dir;
+    float tmax = 100000, tmin = 0;
+    int depth  = 0;
+    bool shadow = false;
+};
+class Intersection
+{
+  public:
+    point3 position;
+    size_t materialIndex = 0;
+    int prim             = -1;
+    float u = 0, v = 0; // barycentric weights of p2, p3
+    bool hit = false;
+};
+// kdtree.h:34.  One ray through the batched GPU entry point -- for callers that still trace ray
+// by ray; anything performance-sensitive should batch through mrt_intersect / mrt_render.
+bool intersectKdTree( Scene* scene, KdTree* tree, Ray* ray, Intersection* intersection );
+
+// Scene + KdTree -> the flat description of mrt.h, with its storage.
+struct FlatScene {
+    mrt_scene_desc desc {};
+    std::vector<uint8_t> obj_kind;
+    std::vector<uint32_t> obj_material, obj_transform, refs, out_of_tree;
+    std::vector<float> tri_p, tri_n, tri_uv, sphere, texels, env_rgb;
+    std::vector<mrt_transform> transforms;
+    std::vector<mrt_material> materials;
+    std::vector<mrt_texture> textures;
+    std::vector<mrt_kdnode> nodes;
+    std::vector<mrt_light> lights;
+    uint32_t tree_depth = 0;
+};
+enum NodeLayout { LAYOUT_PREORDER_PAIRS = 0, LAYOUT_BFS_TOP = 1 };
+FlatScene* flatten( Scene* scene, KdTree* tree, NodeLayout layout = LAYOUT_BFS_TOP );
+
+// rendering/ImageRenderer.h:5-17
+class ImageRenderer
+{
+  public:
+    virtual ~ImageRenderer() = default;
+    virtual void init( std::string& imageName, vec2 resolution, Scene* scene ) = 0;
+    virtual void destroy()                                                      = 0;
+    virtual void run()                                                          = 0;
+
+  protected:
+    Scene* m_scene          = nullptr;
+    std::string m_imageName = "";
+};
+
+// Sibling of the reference's CPURenderer (rendering/CPURenderer.h): same init/run/destroy
+// protocol; spp, depth, seed and device are parameters instead of literals
+// (CPURenderer.cpp:15,18,42).
+class HIPRenderer : public ImageRenderer
+{
+  public:
+    int spp_x = 32, spp_y = 32, maxDepth = 5, device = 0;
+    uint32_t seed = 1;
+    void init( std::string& imageName, vec2 resolution, Scene* scene ) override;
+    void destroy() override;
+    void run() override;
+    const std::vector<float>& linearSum() const { return m_sum; } // [h][w][3] radiance sums
+    const std::vector<float>& image() const { return m_image; }   // averaged + gamma 2.2
+    mrt_render_stats stats {};
+    double seconds = 0;
+
+  private:
+    KdTree* m_kdTree = nullptr;
+    uint32_t m_w = 0, m_h = 0;
+    std::vector<float> m_sum, m_image;
+};
+
+bool savePPM( const char* filename, const float* rgb, uint32_t w, uint32_t h ); // 8-bit, clamp like image.cpp:137
+
+} // namespace mrt

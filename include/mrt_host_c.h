@@ -1,0 +1,85 @@
+/*
+ * mrt_host_c.h -- C view of the host library (libmrt_host.so).
+ *
+ * The host library is the C++ API of mrt_host.hpp (the reference's Scene / Transform / Material /
+ * initKdTree / ImageRenderer surface, see the citations there).  These functions expose the same
+ * operations to callers that cannot include C++ headers; each one names the C++ call it forwards
+ * to.  Handles are opaque pointers owned by the caller and released with the matching *_free.
+ * Functions returning int give -1 on failure and set mrth_last_error().
+ */
+#ifndef MRT_HOST_C_H
+#define MRT_HOST_C_H
+
+#include "mrt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* mrth_last_error( void );
+
+/* Transform (defines.h:67-148) */
+void* mrth_transform_new( void );
+void mrth_transform_free( void* xf );
+void mrth_transform_scale( void* xf, float sx, float sy, float sz );
+void mrth_transform_rotate( void* xf, float ax, float ay, float az, float degrees );
+void mrth_transform_translate( void* xf, float x, float y, float z );
+void mrth_transform_get( void* xf, mrt_transform* out );
+
+/* initScene / freeScene / Scene::CreateMaterial (scene.h:33-37, scene.cpp:130-139) */
+void* mrth_scene_new( void );
+void mrth_scene_free( void* scene );
+int mrth_create_material( void* scene, int mat_type );
+int mrth_material_set( void* scene, int id, const mrt_material* m ); /* texture field ignored */
+int mrth_material_get( void* scene, int id, mrt_material* m );
+int mrth_material_set_checker( void* scene, int id, const float* even3, const float* odd3, void* tex_xf );
+int mrth_material_set_image( void* scene, int id, uint32_t w, uint32_t h, const float* rgb, void* tex_xf );
+int mrth_n_objects( void* scene );
+int mrth_n_materials( void* scene );
+int mrth_n_lights( void* scene );
+
+/* addObjectsFromFile (example_scenes.cpp:22-153) with optional vertex pre-scale and 1->4 subdivision */
+int mrth_add_obj_file( void* scene, const char* path, int default_mat, void* xf, float prescale, int subdivisions );
+/* addObject(scene, initSmoothTriangle / initSphere / new Plane) (scene.cpp:33-110) */
+int mrth_add_triangle( void* scene, const float* p9, const float* n9, const float* fn3, const float* uv6, void* xf, int mat );
+int mrth_add_sphere( void* scene, void* xf, int mat );
+int mrth_add_plane( void* scene, void* xf, int mat );
+/* addLight(scene, new ShapeLight(..., initSphere / initSmoothTriangle)) (example_scenes.cpp:1501-1503, 119-130) */
+int mrth_add_sphere_light( void* scene, void* xf, int mat, const float* color3 );
+int mrth_add_triangle_light( void* scene, const float* p9, const float* n9, const float* fn3, void* xf, int mat, const float* color3 );
+/* new IBL(file); addLight; envLights.push_back (example_scenes.cpp:1384-1392) */
+int mrth_add_ibl_file( void* scene, const char* path, int also_env );
+int mrth_add_ibl_pixels( void* scene, int w, int h, const float* rgb, int also_env );
+/* setSimpleCamera (scene.cpp:151-161) */
+void mrth_set_simple_camera( void* scene, const float* from3, const float* at3, const float* up3, float fov, float w, float h, float radius, float focus );
+
+/* initKdTree (kdtree.h:35); n_threads 0 = all */
+void* mrth_build_kdtree( void* scene, int n_threads );
+void mrth_tree_free( void* tree );
+void mrth_tree_counts( void* tree, int64_t* n_nodes, int64_t* n_refs, int32_t* depth );
+/* pre-order dump of the pointer tree, one entry per node */
+void mrth_tree_dump( void* tree,
+                     uint8_t* leaf,
+                     int32_t* axis,
+                     float* split,
+                     int32_t* left,
+                     int32_t* right,
+                     float* bmin,
+                     float* bmax,
+                     int32_t* ref_off,
+                     int32_t* ref_cnt,
+                     int32_t* refs );
+
+/* flatten(scene, tree, layout): layout 0 = pre-order pairs, 1 = breadth-first top + pre-order */
+void* mrth_flatten( void* scene, void* tree, int layout );
+const mrt_scene_desc* mrth_flat_desc( void* flat );
+uint32_t mrth_flat_depth( void* flat );
+void mrth_flat_free( void* flat );
+
+/* HIPRenderer: init, run, destroy (mrt_host.hpp) */
+int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, float* rgb_sum, mrt_render_stats* stats, double* seconds );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""Builds the native libraries in-tree.
+
+  raytracer_amd/libmrt_hip.so   HIP kernels + C-ABI (hipcc, gfx950; cross-compiles without a GPU)
+  raytracer_amd/libmrt_host.so  C++ host side (g++), links libmrt_hip.so
+  oracle/libmrt_oracle.so       CPU oracle (test infrastructure)
+  oracle/_ref/libmrt_ref.so     the reference's own translation units (only where /root/reference exists)
+
+A library is rebuilt when any of its sources is newer than it.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "raytracer_amd")
+CSRC = os.path.join(PKG, "csrc")
+INC = os.path.join(ROOT, "include")
+ORACLE = os.path.join(ROOT, "oracle")
+REFERENCE = "/root/reference"
+
+HIP_SO = os.path.join(PKG, "libmrt_hip.so")
+HOST_SO = os.path.join(PKG, "libmrt_host.so")
+ORACLE_SO = os.path.join(ORACLE, "libmrt_oracle.so")
+REF_SO = os.path.join(ORACLE, "_ref", "libmrt_ref.so")
+
+# -ffp-contract=off is a correctness flag here: primitive ids are bit-identical to the CPU
+# reference only with unfused fp32 arithmetic.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
+HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fno-fast-math"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _files(d, exts):
+    out = []
+    for base, _, names in os.walk(d):
+        for n in names:
+            if n.endswith(exts):
+                out.append(os.path.join(base, n))
+    return sorted(out)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def build_hip(force=False):
+    srcs = _files(CSRC, (".hip", ".hpp", ".inc")) + _files(INC, (".h",))
+    srcs = [s for s in srcs if os.sep + "host" + os.sep not in s]
+    if force or _newer(HIP_SO, srcs):
+        _run(["hipcc"] + HIP_FLAGS + ["-I" + INC, "-o", HIP_SO, os.path.join(CSRC, "mrt_hip.hip")])
+    return HIP_SO
+
+
+def build_host(force=False):
+    host_dir = os.path.join(CSRC, "host")
+    srcs = _files(host_dir, (".cpp",))
+    deps = srcs + _files(host_dir, (".hpp",)) + _files(INC, (".h", ".hpp")) + [HIP_SO]
+    if force or _newer(HOST_SO, deps):
+        _run(["g++"] + HOST_FLAGS + ["-I" + INC, "-I" + host_dir, "-o", HOST_SO] + srcs +
+             ["-L" + PKG, "-lmrt_hip", "-Wl,-rpath,$ORIGIN"])
+    return HOST_SO
+
+
+def build_oracle(force=False):
+    if force or _newer(ORACLE_SO, _files(ORACLE, (".cpp", ".h", ".inc")) + _files(INC, (".h",))):
+        _run(["make", "-C", ORACLE, "oracle"] + (["-B"] if force else []))
+    return ORACLE_SO
+
+
+def build_ref(force=False):
+    """Only in the build container: the reference sources do not travel."""
+    if not os.path.isdir(os.path.join(REFERENCE, "src")):
+        return None
+    if force or _newer(REF_SO, [os.path.join(ORACLE, "ref", "ref_harness.cpp")]):
+        _run(["make", "-C", ORACLE, "ref"] + (["-B"] if force else []))
+    return REF_SO
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_host(force)
+    build_oracle(force)
+    build_ref(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("built:", HIP_SO, HOST_SO, ORACLE_SO, REF_SO if os.path.exists(REF_SO) else "(no reference build)")

@@ -1,0 +1,275 @@
+// initKdTree for the GPU backend: the reference's SAH kd-tree construction (kdtree.cpp:54-464)
+// producing the SAME tree -- node for node, split for split, leaf list for leaf list -- because
+// the order of primitives inside leaves and the position of every split decide which primitive
+// wins a tie, and hit ids must match the reference bit for bit.
+//
+// What is kept exactly: the event generation order, std::sort on the event position alone (the
+// permutation among equal positions is whatever libstdc++'s introsort yields), the sweep whose
+// index is advanced both inside the three while loops and by the for header (so one event after
+// every group is skipped), the strict-interior candidate test, the float cost model
+// lambda * (1 + 1.5 * (pl*nl + pr*nr)), termination at cost > 1.5 * N in double, distribution to
+// children by closed bounding-box overlap, no depth limit.
+//
+// What is different from the reference: world-space boxes are computed once per object instead
+// of once per node, axis and object; the three per-axis event lists are generated in one pass;
+// sibling subtrees are built by OpenMP tasks.
+#include "host_math.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <omp.h>
+
+namespace mrt {
+
+KdTreeNode::~KdTreeNode() {
+    delete left;
+    delete right;
+}
+KdTree::~KdTree() {
+    delete root;
+}
+
+namespace {
+
+struct Event {
+    float b;
+    int type;
+};
+enum { STARTING = 0, LYING = 1, ENDING = 2 };
+bool comp_events( Event i, Event j ) {
+    return i.b < j.b;
+}
+
+struct Prim {
+    int kind;
+    vec3 bmin, bmax; // triangle: bounds of the world-space vertices; sphere: centre -/+ radius
+    vec3 center;
+    float radius;
+};
+
+float surfaceArea( const vec3& mn, const vec3& mx ) {
+    float dx = mx.x - mn.x;
+    float dy = mx.y - mn.y;
+    float dz = mx.z - mn.z;
+    return 2 * dx * dy + 2 * dx * dz + 2 * dy * dz;
+}
+float cost( int nl, int nr, float pl, float pr ) {
+    float Kt = 1.0, Ki = 1.5;
+    float lambda_p = ( nl == 0 || nr == 0 ) ? 0.8f : 1.f;
+    return ( lambda_p * ( Kt + Ki * ( pl * nl + pr * nr ) ) );
+}
+float sah( const vec3& mn, const vec3& mx, float area, float p, int nl, int nr, int np, int k ) {
+    vec3 max_vl = mx, min_vr = mn;
+    max_vl[k] = p;
+    min_vr[k] = p;
+    float pl  = surfaceArea( mn, max_vl ) / area;
+    float pr  = surfaceArea( min_vr, mx ) / area;
+    float cpl = cost( nl + np, nr, pl, pr );
+    float cpr = cost( nl, nr + np, pl, pr );
+    return ( cpl < cpr ) ? cpl : cpr;
+}
+
+struct Builder {
+    std::vector<Prim> prims;
+    int task_cutoff = 2048;
+
+    void clipped( const Prim& p, const vec3& mn, const vec3& mx, vec3& minb, vec3& maxb ) const {
+        minb = p.bmin;
+        maxb = p.bmax;
+        for ( int k = 0; k < 3; k++ ) {
+            if ( mn[k] > minb[k] ) minb[k] = mn[k];
+            if ( mx[k] < maxb[k] ) maxb[k] = mx[k];
+        }
+    }
+
+    // kdtree.cpp:316-390
+    void findPlane( const KdTreeNode* node, std::vector<Event>* ev, float& p_, int& k_, float& c_ ) const {
+        c_ = INFINITY;
+        p_ = 0;
+        for ( int k = 0; k < 3; k++ )
+            ev[k].clear();
+        for ( int obj : node->objects ) {
+            vec3 minb, maxb;
+            clipped( prims[obj], node->min, node->max, minb, maxb );
+            float dx = maxb.x - minb.x, dy = maxb.y - minb.y, dz = maxb.z - minb.z;
+            bool planar = dx <= 0.001 || dy <= 0.001 || dz <= 0.001;
+            for ( int k = 0; k < 3; k++ ) {
+                if ( planar ) ev[k].push_back( Event { minb[k], LYING } );
+                else {
+                    ev[k].push_back( Event { minb[k], STARTING } );
+                    ev[k].push_back( Event { maxb[k], ENDING } );
+                }
+            }
+        }
+        const float area = surfaceArea( node->min, node->max );
+        for ( int k = 0; k < 3; k++ ) {
+            std::vector<Event>& events = ev[k];
+            std::sort( events.begin(), events.end(), comp_events );
+            const size_t n = events.size();
+            int nl = 0, np = 0, nr = (int)node->objects.size();
+            for ( size_t i = 0; i < n; i++ ) {
+                float p       = events[i].b;
+                int pStarting = 0, pEnding = 0, pLying = 0;
+                while ( i < n && events[i].b == p && events[i].type == ENDING ) {
+                    pEnding++;
+                    i++;
+                }
+                while ( i < n && events[i].b == p && events[i].type == LYING ) {
+                    pLying++;
+                    i++;
+                }
+                while ( i < n && events[i].b == p && events[i].type == STARTING ) {
+                    pStarting++;
+                    i++;
+                }
+                np = pLying;
+                nr -= pLying;
+                nr -= pEnding;
+                float c = sah( node->min, node->max, area, p, nl, nr, np, k );
+                if ( c < c_ && !( p <= node->min[k] ) && !( p >= node->max[k] ) ) {
+                    c_ = c;
+                    p_ = p;
+                    k_ = k;
+                }
+                nl += pStarting;
+                nl += pLying;
+                np = 0;
+            }
+        }
+    }
+
+    static bool boxOverlap( const vec3& mn, const vec3& mx, const vec3& aMin, const vec3& aMax ) {
+        return !( ( mn.x > aMax.x ) || ( mx.x < aMin.x ) || ( mn.y > aMax.y ) || ( mx.y < aMin.y ) || ( mn.z > aMax.z ) || ( mx.z < aMin.z ) );
+    }
+    static bool sphereOverlap( const vec3& c, float r, const vec3& aMin, const vec3& aMax ) {
+        vec3 q;
+        for ( int k = 0; k < 3; k++ ) {
+            float v = ( c[k] < aMin[k] ) ? aMin[k] : c[k]; // max(c, aMin)
+            q[k]    = ( aMax[k] < v ) ? aMax[k] : v;       // min(., aMax)
+        }
+        vec3 seg = q - c;
+        return dot( seg, seg ) < ( r * r );
+    }
+
+    // kdtree.cpp:392-464
+    void subdivide( KdTreeNode* node ) const {
+        static thread_local std::vector<Event> ev[3];
+        float p = 0, c = 0;
+        int axis = 0;
+        findPlane( node, ev, p, axis, c );
+        if ( c == INFINITY || c > 1.5 * node->objects.size() ) {
+            node->leaf = true;
+            return;
+        }
+        KdTreeNode* l = new KdTreeNode();
+        KdTreeNode* r = new KdTreeNode();
+        l->depth = r->depth = node->depth + 1;
+        l->min = r->min = node->min;
+        l->max = r->max = node->max;
+        node->split     = p;
+        node->axis      = axis;
+        l->max[axis]    = p;
+        r->min[axis]    = p;
+        node->left      = l;
+        node->right     = r;
+        for ( int obj : node->objects ) {
+            const Prim& pr = prims[obj];
+            bool inl, inr;
+            if ( pr.kind == SPHERE ) {
+                inl = sphereOverlap( pr.center, pr.radius, l->min, l->max );
+                inr = sphereOverlap( pr.center, pr.radius, r->min, r->max );
+            }
+            else {
+                inl = boxOverlap( pr.bmin, pr.bmax, l->min, l->max );
+                inr = boxOverlap( pr.bmin, pr.bmax, r->min, r->max );
+            }
+            if ( inl ) l->objects.push_back( obj );
+            if ( inr ) r->objects.push_back( obj );
+        }
+        std::vector<int>().swap( node->objects );
+
+        const bool spawn = (int)l->objects.size() + (int)r->objects.size() >= task_cutoff;
+#pragma omp task if ( spawn ) firstprivate( l )
+        subdivide( l );
+        subdivide( r );
+#pragma omp taskwait
+    }
+};
+
+} // namespace
+
+KdTree* initKdTree( Scene* scene, int n_threads ) {
+    KdTree* tree = new KdTree();
+    Builder b;
+    b.prims.resize( scene->objects.size() );
+    for ( size_t i = 0; i < scene->objects.size(); i++ ) {
+        const Object* o = scene->objects[i];
+        Prim& p         = b.prims[i];
+        p.kind          = o->geom.type;
+        if ( o->geom.type == PLANE ) { tree->outOfTree.push_back( (int)i ); }
+        else if ( o->geom.type == SPHERE ) {
+            tree->inTree.push_back( (int)i );
+            p.center = o->geom.sphere.center;
+            p.radius = o->geom.sphere.radius;
+            p.bmin   = vec3( p.center.x - p.radius, p.center.y - p.radius, p.center.z - p.radius );
+            p.bmax   = vec3( p.center.x + p.radius, p.center.y + p.radius, p.center.z + p.radius );
+        }
+        else if ( o->geom.type == TRIANGLE ) {
+            tree->inTree.push_back( (int)i );
+            vec3 v0 = o->transform.transformFrom( o->geom.triangle.p1 );
+            vec3 v1 = o->transform.transformFrom( o->geom.triangle.p2 );
+            vec3 v2 = o->transform.transformFrom( o->geom.triangle.p3 );
+            p.bmin  = vec3( std::min( v0.x, std::min( v1.x, v2.x ) ), std::min( v0.y, std::min( v1.y, v2.y ) ), std::min( v0.z, std::min( v1.z, v2.z ) ) );
+            p.bmax  = vec3( std::max( v0.x, std::max( v1.x, v2.x ) ), std::max( v0.y, std::max( v1.y, v2.y ) ), std::max( v0.z, std::max( v1.z, v2.z ) ) );
+        }
+    }
+    tree->objLimit = scene->objects.size() * sizeof( Object );
+    if ( tree->inTree.empty() ) return tree;
+
+    // Root box (kdtree.cpp:79-146).  A sphere contributes the centre recomputed through its
+    // transform +/- the radius; a triangle its three world-space vertices.
+    bool first = true;
+    vec3 mn, mx;
+    for ( int i : tree->inTree ) {
+        const Object* o = scene->objects[i];
+        vec3 lo, hi;
+        if ( o->geom.type == SPHERE ) {
+            vec3 c  = o->transform.transformFrom( vec3( 0.f ) );
+            float r = o->geom.sphere.radius;
+            lo      = vec3( c.x - r, c.y - r, c.z - r );
+            hi      = vec3( c.x + r, c.y + r, c.z + r );
+        }
+        else {
+            lo = b.prims[i].bmin;
+            hi = b.prims[i].bmax;
+        }
+        if ( first ) {
+            mn    = lo;
+            mx    = hi;
+            first = false;
+        }
+        else {
+            for ( int k = 0; k < 3; k++ ) {
+                if ( lo[k] < mn[k] ) mn[k] = lo[k];
+                if ( mx[k] < hi[k] ) mx[k] = hi[k];
+            }
+        }
+    }
+    KdTreeNode* root = new KdTreeNode();
+    root->min        = mn - 1.f;
+    root->max        = mx + 1.f;
+    root->objects.assign( tree->inTree.begin(), tree->inTree.end() );
+    tree->root = root;
+
+    if ( n_threads < 1 ) n_threads = omp_get_max_threads();
+#pragma omp parallel num_threads( n_threads )
+#pragma omp single
+    b.subdivide( root );
+    return tree;
+}
+
+KdTree* initKdTree( Scene* scene ) {
+    return initKdTree( scene, 0 );
+}
+
+} // namespace mrt

@@ -1,0 +1,88 @@
+// HIPRenderer (the GPU sibling of the reference's CPURenderer) and the single-ray
+// intersectKdTree convenience entry; both go through the C-ABI of mrt.h.
+#include "host_math.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+namespace mrt {
+
+static mrt_scene* device_scene_for( Scene* scene, KdTree* tree, int device ) {
+    if ( !tree->flat ) tree->flat = flatten( scene, tree );
+    if ( !tree->device_scene ) {
+        mrt_status st = mrt_scene_create( &tree->flat->desc, device, &tree->device_scene );
+        if ( st != MRT_OK ) throw std::runtime_error( std::string( "mrt_scene_create: " ) + mrt_last_error() );
+    }
+    return tree->device_scene;
+}
+
+bool intersectKdTree( Scene* scene, KdTree* tree, Ray* ray, Intersection* intersection ) {
+    mrt_scene* ds = device_scene_for( scene, tree, 0 );
+    mrt_rays r { &ray->orig.x, &ray->orig.y, &ray->orig.z, &ray->dir.x, &ray->dir.y, &ray->dir.z, &ray->tmin, &ray->tmax };
+    int32_t prim = -1;
+    float t = 0, u = 0, v = 0;
+    mrt_hits h { &prim, &t, &u, &v };
+    mrt_status st = mrt_intersect( ds, 1, &r, &h, ray->shadow ? MRT_ANY_HIT : MRT_CLOSEST_HIT, MRT_BUF_HOST, nullptr, nullptr );
+    if ( st != MRT_OK ) throw std::runtime_error( std::string( "mrt_intersect: " ) + mrt_last_error() );
+    if ( prim < 0 ) return false;
+    ray->tmax                   = t;
+    intersection->hit           = true;
+    intersection->prim          = prim;
+    intersection->u             = u;
+    intersection->v             = v;
+    intersection->position      = ray->orig + ( t * ray->dir );
+    intersection->materialIndex = scene->objects[prim]->m_MaterialIndex;
+    return true;
+}
+
+void HIPRenderer::init( std::string& imageName, vec2 resolution, Scene* scene ) {
+    m_imageName = imageName;
+    m_scene     = scene;
+    m_w         = (uint32_t)resolution.x;
+    m_h         = (uint32_t)resolution.y;
+    m_sum.assign( (size_t)m_w * m_h * 3, 0.f );
+    m_image.assign( (size_t)m_w * m_h * 3, 0.f );
+    std::printf( "Output resolution: %ux%u\n", m_w, m_h );
+    m_kdTree = initKdTree( m_scene );
+    std::printf( "Spp: %d\n", spp_x * spp_y );
+    device_scene_for( m_scene, m_kdTree, device );
+}
+
+void HIPRenderer::destroy() {
+    if ( m_kdTree ) {
+        if ( m_kdTree->device_scene ) mrt_scene_destroy( m_kdTree->device_scene );
+        delete m_kdTree->flat;
+        delete m_kdTree;
+        m_kdTree = nullptr;
+    }
+    m_sum.clear();
+    m_image.clear();
+}
+
+void HIPRenderer::run() {
+    auto t0 = std::chrono::steady_clock::now();
+    mrt_render_params p {};
+    p.width        = m_w;
+    p.height       = m_h;
+    p.spp_x        = (uint32_t)spp_x;
+    p.spp_y        = (uint32_t)spp_y;
+    p.sample_begin = 0;
+    p.sample_end   = (uint32_t)( spp_x * spp_y );
+    p.max_depth    = (uint32_t)maxDepth;
+    p.seed         = seed;
+    p.row_begin    = 0;
+    p.row_end      = m_h;
+    mrt_status st  = mrt_render( m_kdTree->device_scene, &p, m_sum.data(), MRT_BUF_HOST, nullptr, &stats );
+    if ( st != MRT_OK ) throw std::runtime_error( std::string( "mrt_render: " ) + mrt_last_error() );
+    // average + gamma (CPURenderer.cpp:64-69)
+    const float spp = (float)( spp_x * spp_y );
+    for ( size_t i = 0; i < m_sum.size(); i++ )
+        m_image[i] = powf( m_sum[i] / spp, 1.0f / 2.2 );
+    seconds = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+    std::printf( "Rendering took %gs\n", seconds );
+    if ( !m_imageName.empty() ) savePPM( ( m_imageName + ".ppm" ).c_str(), m_image.data(), m_w, m_h );
+}
+
+} // namespace mrt

@@ -1,0 +1,557 @@
+// Host-side Scene / Transform / Camera / loaders of the GPU backend (see mrt_host.hpp).
+#include "host_math.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+namespace mrt {
+
+static const double kPi = 3.14159265358979323846;
+
+// ------------------------------------------------------------------ Transform (defines.h:67-148)
+vec3 Transform::transformTo( vec3 const& p ) const {
+    return mul( m_invTransform, p - m_translation );
+}
+vec3 Transform::transformFrom( vec3 const& p ) const {
+    return mul( m_transform, p ) + m_translation;
+}
+vec3 Transform::vectorTransformFrom( vec3 const& dir ) const {
+    const mat3& m = m_invTransform;
+    return vec3( dot( vec3( m.c[0][0], m.c[0][1], m.c[0][2] ), dir ),
+                 dot( vec3( m.c[1][0], m.c[1][1], m.c[1][2] ), dir ),
+                 dot( vec3( m.c[2][0], m.c[2][1], m.c[2][2] ), dir ) );
+}
+void Transform::translate( vec3 const& p ) {
+    m_translation = m_translation + p;
+}
+void Transform::transform( mat3 const& m ) {
+    m_transform    = mul( m, m_transform );
+    m_translation  = mul( m, m_translation );
+    m_invTransform = inverse( m_transform );
+}
+void Transform::scale( float sx, float sy, float sz ) {
+    mat3 m    = zero3();
+    m.c[0][0] = sx;
+    m.c[1][1] = sy;
+    m.c[2][2] = sz;
+    transform( m );
+}
+void Transform::rotate( vec3 const& axis, float degrees ) {
+    // degrees_to_radians (defines.h:53-55) evaluates in double and returns a float
+    float theta = (float)( (double)degrees * kPi / (double)180.0f );
+    float c     = std::cos( theta );
+    if ( c == 1 ) return;
+    float s   = std::sin( theta );
+    float t   = 1 - c;
+    float tx  = t * axis.x;
+    float ty  = t * axis.y;
+    float tz  = t * axis.z;
+    float txy = tx * axis.y;
+    float txz = tx * axis.z;
+    float tyz = ty * axis.z;
+    float sx  = s * axis.x;
+    float sy  = s * axis.y;
+    float sz  = s * axis.z;
+    mat3 m    = zero3();
+    m.c[0][0] = tx * axis.x + c;
+    m.c[0][1] = txy + sz;
+    m.c[0][2] = txz - sy;
+    m.c[1][0] = txy - sz;
+    m.c[1][1] = ty * axis.y + c;
+    m.c[1][2] = tyz + sx;
+    m.c[2][0] = txz + sy;
+    m.c[2][1] = tyz - sx;
+    m.c[2][2] = tz * axis.z + c;
+    transform( m );
+}
+bool Transform::operator==( Transform const& o ) const {
+    return std::memcmp( &m_transform, &o.m_transform, sizeof( mat3 ) ) == 0 &&
+           std::memcmp( &m_invTransform, &o.m_invTransform, sizeof( mat3 ) ) == 0 &&
+           std::memcmp( &m_translation, &o.m_translation, sizeof( vec3 ) ) == 0;
+}
+bool Transform::isIdentity() const {
+    return *this == Transform();
+}
+
+// ------------------------------------------------------------------ Material (Material.cpp:241-262)
+Material::Material( size_t UID, MaterialModel matModel, MatType matType ) : m_MatModel( matModel ), m_UID( UID ) {
+    if ( matModel == MaterialModel::COOK_TORRANCE ) {
+        m_IOR       = 1.0;
+        m_roughness = 0.1;
+        m_metalness = 0.001f;
+        m_albedo    = color3( 1.f );
+        m_MatType   = matType;
+    }
+    else {
+        m_IOR    = 1.0;
+        m_albedo = color3( 0.5f );
+    }
+}
+
+// ------------------------------------------------------------------ scene.cpp:33-175
+Scene::~Scene() {
+    for ( auto* o : objects )
+        delete o;
+    for ( auto* l : lights )
+        delete l;
+    for ( auto* t : owned_textures )
+        delete t;
+    delete cam;
+}
+Scene* initScene() {
+    return new Scene;
+}
+void freeScene( Scene* scene ) {
+    delete scene;
+}
+Object* initSphere( int materialIndex, Transform transform ) {
+    auto ret                = new Object( materialIndex, transform );
+    ret->geom.type          = SPHERE;
+    ret->geom.sphere.center = transform.transformFrom( vec3( 0.f ) );
+    const mat3& m           = transform.getTransform();
+    float s0 = dot( vec3( m.c[0][0], m.c[0][1], m.c[0][2] ), vec3( m.c[0][0], m.c[0][1], m.c[0][2] ) );
+    float s1 = dot( vec3( m.c[1][0], m.c[1][1], m.c[1][2] ), vec3( m.c[1][0], m.c[1][1], m.c[1][2] ) );
+    float s2 = dot( vec3( m.c[2][0], m.c[2][1], m.c[2][2] ), vec3( m.c[2][0], m.c[2][1], m.c[2][2] ) );
+    ret->geom.sphere.radius = 1.f * std::sqrt( std::max( s0, std::max( s1, s2 ) ) );
+    return ret;
+}
+Object* initSmoothTriangle( vec3 p1, vec3 p2, vec3 p3, vec3 n, vec2 t[3], vec3 n1, vec3 n2, vec3 n3, Transform transform, int materialIndex ) {
+    auto ret                  = new Object( materialIndex, transform );
+    ret->geom.type            = TRIANGLE;
+    ret->geom.triangle.p1     = p1;
+    ret->geom.triangle.p2     = p2;
+    ret->geom.triangle.p3     = p3;
+    ret->geom.triangle.n1     = n1;
+    ret->geom.triangle.n2     = n2;
+    ret->geom.triangle.n3     = n3;
+    ret->geom.triangle.normal = n;
+    ret->geom.triangle.tex[0] = t[0];
+    ret->geom.triangle.tex[1] = t[1];
+    ret->geom.triangle.tex[2] = t[2];
+    return ret;
+}
+Object* initTriangle( vec3 p1, vec3 p2, vec3 p3, vec3 n, vec2 t[3], Transform transform, int materialIndex ) {
+    // The reference leaves n1..n3 unset here (scene.cpp:65-83) and then interpolates them
+    // (triangle.cpp:41); the face normal is the only defined choice.
+    return initSmoothTriangle( p1, p2, p3, n, t, n, n, n, transform, materialIndex );
+}
+void addObject( Scene* scene, Object* obj ) {
+    scene->objects.push_back( obj );
+}
+void addLight( Scene* scene, Light* light ) {
+    scene->lights.push_back( light );
+}
+void setSimpleCamera( Scene* scene, point3 position, vec3 at, vec3 up, float fov, float w, float h, float radius, float focusDist ) {
+    delete scene->cam;
+    scene->cam = new SimpleCamera( position, at, up, fov, ( w / h ), (int)w, (int)h, radius, focusDist );
+}
+
+// ------------------------------------------------------------------ SimpleCamera (Camera.cpp:5-35)
+SimpleCamera::SimpleCamera( point3 lookfrom, point3 lookat, vec3 vup, float vfov, float aspect_ratio, int width, int height, float lensRadius, float focalDistance ) {
+    pos             = lookfrom;
+    fov             = vfov;
+    aspect          = aspect_ratio;
+    m_lensRadius    = lensRadius;
+    m_focalDistance = focalDistance;
+    imgWidth        = (float)width;
+    imgHeight       = (float)height;
+    dir             = lookat;
+    dir             = dir - pos;
+    dir             = normalize( dir );
+    xDir            = cross( dir, vup );
+    up              = normalize( cross( xDir, dir ) );
+    left            = normalize( cross( up, dir ) );
+    float radfov    = (float)( (double)( fov * (float)kPi ) / 180.0 );
+    l               = m_focalDistance;
+    h               = std::tan( radfov * .5f ) * ( 2.0f * l );
+    w               = h * imgWidth / (float)imgHeight;
+    point3 B         = pos + ( l * dir ) + ( h / 2.0f * up );
+    nearPlaneTopLeft = B + w / 2.0f * ( left );
+    dXPixel          = -left * ( w / (float)imgWidth );
+    dYPixel          = -up * ( w / (float)imgWidth );
+}
+
+// ------------------------------------------------------------------ textures
+texture* checker_texture( color3 c1, color3 c2 ) {
+    auto* t = new texture;
+    t->kind = MRT_TEX_CHECKER;
+    t->even = c1;
+    t->odd  = c2;
+    return t;
+}
+// Binary PPM (P6, maxval 255) reader; the value mapping is loadPng's, byte / 255.f (image.cpp:30-34).
+texture* image_texture( const char* filename ) {
+    FILE* f = std::fopen( filename, "rb" );
+    if ( !f ) return nullptr;
+    char magic[3] = { 0 };
+    int w = 0, h = 0, maxv = 0;
+    if ( std::fscanf( f, "%2s %d %d %d", magic, &w, &h, &maxv ) != 4 || std::strcmp( magic, "P6" ) != 0 || maxv != 255 ) {
+        std::fclose( f );
+        return nullptr;
+    }
+    std::fgetc( f );
+    std::vector<unsigned char> buf( (size_t)w * h * 3 );
+    size_t got = std::fread( buf.data(), 1, buf.size(), f );
+    std::fclose( f );
+    if ( got != buf.size() ) return nullptr;
+    auto* t   = new texture;
+    t->kind   = MRT_TEX_IMAGE;
+    t->width  = w;
+    t->height = h;
+    t->texels.resize( buf.size() );
+    for ( size_t i = 0; i < buf.size(); i++ )
+        t->texels[i] = (float)(unsigned int)buf[i] / 255.f;
+    return t;
+}
+
+// ------------------------------------------------------------------ IBL: Radiance RGBE reader
+// Pixel decode is the one stb_image's stbi_loadf applies to .hdr files, which the reference calls
+// (Light.h:205): value = mantissa * 2^(exponent - 136), exponent 0 -> 0; new-style RLE scanlines.
+static void rgbe_to_float( const unsigned char* in, float* out ) {
+    if ( in[3] != 0 ) {
+        float f1 = std::ldexp( 1.0f, (int)in[3] - ( 128 + 8 ) );
+        out[0]   = in[0] * f1;
+        out[1]   = in[1] * f1;
+        out[2]   = in[2] * f1;
+    }
+    else { out[0] = out[1] = out[2] = 0.f; }
+}
+IBL::IBL( int width, int height, std::vector<float> rgb ) : m_width( width ), m_height( height ), m_pixels( std::move( rgb ) ) {
+    m_color = color3( 0.f );
+}
+IBL::IBL( const std::string& filename ) {
+    m_color = color3( 0.f );
+    std::ifstream f( filename, std::ios::binary );
+    if ( !f ) throw std::runtime_error( "IBL: cannot open " + filename );
+    std::string line;
+    std::getline( f, line );
+    if ( line.rfind( "#?RADIANCE", 0 ) != 0 && line.rfind( "#?RGBE", 0 ) != 0 ) throw std::runtime_error( "IBL: not a Radiance file: " + filename );
+    bool fmt = false;
+    while ( std::getline( f, line ) ) {
+        if ( line.empty() ) break;
+        if ( line == "FORMAT=32-bit_rle_rgbe" ) fmt = true;
+    }
+    if ( !fmt ) throw std::runtime_error( "IBL: unsupported format in " + filename );
+    std::getline( f, line );
+    int w = 0, h = 0;
+    if ( std::sscanf( line.c_str(), "-Y %d +X %d", &h, &w ) != 2 ) throw std::runtime_error( "IBL: unsupported orientation in " + filename );
+    m_width  = w;
+    m_height = h;
+    m_pixels.resize( (size_t)w * h * 3 );
+    std::vector<unsigned char> rest( ( std::istreambuf_iterator<char>( f ) ), std::istreambuf_iterator<char>() );
+    size_t p = 0;
+    auto need = [&]( size_t n ) {
+        if ( p + n > rest.size() ) throw std::runtime_error( "IBL: truncated file " + filename );
+    };
+    std::vector<unsigned char> scan( (size_t)w * 4 );
+    if ( w < 8 || w >= 32768 ) { // flat data
+        for ( size_t i = 0; i < (size_t)w * h; i++ ) {
+            need( 4 );
+            rgbe_to_float( &rest[p], &m_pixels[3 * i] );
+            p += 4;
+        }
+        return;
+    }
+    for ( int j = 0; j < h; j++ ) {
+        need( 4 );
+        int c1 = rest[p], c2 = rest[p + 1], len = rest[p + 2];
+        if ( c1 != 2 || c2 != 2 || ( len & 0x80 ) ) { // not run-length encoded: flat from here
+            if ( j != 0 ) throw std::runtime_error( "IBL: mixed encoding in " + filename );
+            for ( size_t i = 0; i < (size_t)w * h; i++ ) {
+                need( 4 );
+                rgbe_to_float( &rest[p], &m_pixels[3 * i] );
+                p += 4;
+            }
+            return;
+        }
+        len = ( len << 8 ) | rest[p + 3];
+        p += 4;
+        if ( len != w ) throw std::runtime_error( "IBL: bad scanline width in " + filename );
+        for ( int k = 0; k < 4; k++ ) {
+            int i = 0;
+            while ( i < w ) {
+                need( 1 );
+                int count = rest[p++];
+                if ( count > 128 ) {
+                    count -= 128;
+                    need( 1 );
+                    unsigned char value = rest[p++];
+                    if ( i + count > w ) throw std::runtime_error( "IBL: corrupt run in " + filename );
+                    for ( int z = 0; z < count; z++ )
+                        scan[( i++ ) * 4 + k] = value;
+                }
+                else {
+                    need( count );
+                    if ( count == 0 || i + count > w ) throw std::runtime_error( "IBL: corrupt run in " + filename );
+                    for ( int z = 0; z < count; z++ )
+                        scan[( i++ ) * 4 + k] = rest[p++];
+                }
+            }
+        }
+        for ( int i = 0; i < w; i++ )
+            rgbe_to_float( &scan[i * 4], &m_pixels[( (size_t)j * w + i ) * 3] );
+    }
+}
+
+// ------------------------------------------------------------------ OBJ / MTL
+namespace {
+
+struct MtlRec {
+    float Kd[3] = { 0.6f, 0.6f, 0.6f }, Ke[3] = { 0, 0, 0 }, Ks[3] = { 0, 0, 0 };
+    float Ni    = 1.f;
+};
+
+struct ObjData {
+    std::vector<float> v, vn, vt;
+    struct Corner {
+        int v, vt, vn;
+    };
+    std::vector<Corner> corners;  // 3 per triangle (polygons are fanned like tinyobj's triangulate)
+    std::vector<int> face_mtl;    // per triangle, -1 = none
+    std::vector<MtlRec> mtls;
+};
+
+bool parse_mtl( const std::string& path, std::vector<MtlRec>& out, std::map<std::string, int>& names ) {
+    std::ifstream f( path );
+    if ( !f ) return false;
+    std::string line;
+    MtlRec* cur = nullptr;
+    while ( std::getline( f, line ) ) {
+        std::istringstream ss( line );
+        std::string tag;
+        if ( !( ss >> tag ) ) continue;
+        if ( tag == "newmtl" ) {
+            std::string name;
+            ss >> name;
+            names[name] = (int)out.size();
+            out.emplace_back();
+            cur = &out.back();
+        }
+        else if ( cur ) {
+            auto rd3 = [&]( float* d ) {
+                double a = 0, b = 0, c = 0;
+                ss >> a >> b >> c;
+                d[0] = (float)a;
+                d[1] = (float)b;
+                d[2] = (float)c;
+            };
+            if ( tag == "Kd" ) rd3( cur->Kd );
+            else if ( tag == "Ke" ) rd3( cur->Ke );
+            else if ( tag == "Ks" ) rd3( cur->Ks );
+            else if ( tag == "Ni" ) {
+                double a = 1;
+                ss >> a;
+                cur->Ni = (float)a;
+            }
+        }
+    }
+    return true;
+}
+
+int fix_index( int idx, size_t n ) { // OBJ: 1-based, negative = relative to the end
+    if ( idx > 0 ) return idx - 1;
+    if ( idx < 0 ) return (int)n + idx;
+    return -1;
+}
+
+void parse_obj( const char* filename, ObjData& d ) {
+    std::ifstream f( filename );
+    if ( !f ) throw std::runtime_error( std::string( "cannot open OBJ file " ) + filename );
+    std::string dir = filename;
+    size_t slash    = dir.find_last_of( "/\\" );
+    dir             = ( slash == std::string::npos ) ? std::string( "" ) : dir.substr( 0, slash + 1 );
+    std::map<std::string, int> mtl_names;
+    int cur_mtl = -1;
+    std::string line;
+    while ( std::getline( f, line ) ) {
+        const char* s = line.c_str();
+        while ( *s == ' ' || *s == '\t' )
+            s++;
+        if ( s[0] == 'v' && ( s[1] == ' ' || s[1] == '\t' ) ) {
+            char* e;
+            for ( int k = 0; k < 3; k++ ) {
+                d.v.push_back( (float)std::strtod( s + ( k == 0 ? 1 : 0 ), &e ) );
+                s = e;
+            }
+        }
+        else if ( s[0] == 'v' && s[1] == 'n' ) {
+            char* e;
+            s += 2;
+            for ( int k = 0; k < 3; k++ ) {
+                d.vn.push_back( (float)std::strtod( s, &e ) );
+                s = e;
+            }
+        }
+        else if ( s[0] == 'v' && s[1] == 't' ) {
+            char* e;
+            s += 2;
+            for ( int k = 0; k < 2; k++ ) {
+                d.vt.push_back( (float)std::strtod( s, &e ) );
+                s = e;
+            }
+        }
+        else if ( s[0] == 'f' && ( s[1] == ' ' || s[1] == '\t' ) ) {
+            s += 1;
+            std::vector<ObjData::Corner> poly;
+            while ( *s ) {
+                while ( *s == ' ' || *s == '\t' || *s == '\r' )
+                    s++;
+                if ( !*s ) break;
+                char* e;
+                ObjData::Corner c { -1, -1, -1 };
+                c.v = fix_index( (int)std::strtol( s, &e, 10 ), d.v.size() / 3 );
+                s   = e;
+                if ( *s == '/' ) {
+                    s++;
+                    if ( *s != '/' ) {
+                        c.vt = fix_index( (int)std::strtol( s, &e, 10 ), d.vt.size() / 2 );
+                        s    = e;
+                    }
+                    if ( *s == '/' ) {
+                        s++;
+                        c.vn = fix_index( (int)std::strtol( s, &e, 10 ), d.vn.size() / 3 );
+                        s    = e;
+                    }
+                }
+                poly.push_back( c );
+            }
+            for ( size_t k = 2; k < poly.size(); k++ ) {
+                d.corners.push_back( poly[0] );
+                d.corners.push_back( poly[k - 1] );
+                d.corners.push_back( poly[k] );
+                d.face_mtl.push_back( cur_mtl );
+            }
+        }
+        else if ( std::strncmp( s, "mtllib", 6 ) == 0 ) {
+            std::istringstream ss( s + 6 );
+            std::string name;
+            ss >> name;
+            parse_mtl( dir + name, d.mtls, mtl_names );
+        }
+        else if ( std::strncmp( s, "usemtl", 6 ) == 0 ) {
+            std::istringstream ss( s + 6 );
+            std::string name;
+            ss >> name;
+            auto it = mtl_names.find( name );
+            cur_mtl = ( it == mtl_names.end() ) ? -1 : it->second;
+        }
+    }
+}
+
+struct Tri {
+    vec3 p[3], n[3];
+    vec2 t[3];
+    bool has_n;
+    int mtl;
+};
+
+void subdivide_once( std::vector<Tri>& tris ) {
+    std::vector<Tri> out;
+    out.reserve( tris.size() * 4 );
+    auto mid3 = []( vec3 a, vec3 b ) { return ( a + b ) * 0.5f; };
+    auto mid2 = []( vec2 a, vec2 b ) { return vec2 { ( a.x + b.x ) * 0.5f, ( a.y + b.y ) * 0.5f }; };
+    for ( const Tri& t : tris ) {
+        vec3 m01 = mid3( t.p[0], t.p[1] ), m12 = mid3( t.p[1], t.p[2] ), m20 = mid3( t.p[2], t.p[0] );
+        vec3 n01 = mid3( t.n[0], t.n[1] ), n12 = mid3( t.n[1], t.n[2] ), n20 = mid3( t.n[2], t.n[0] );
+        vec2 t01 = mid2( t.t[0], t.t[1] ), t12 = mid2( t.t[1], t.t[2] ), t20 = mid2( t.t[2], t.t[0] );
+        Tri a    = t, b = t, c = t, m = t;
+        a.p[1] = m01, a.p[2] = m20, a.n[1] = n01, a.n[2] = n20, a.t[1] = t01, a.t[2] = t20;
+        b.p[0] = m01, b.p[2] = m12, b.n[0] = n01, b.n[2] = n12, b.t[0] = t01, b.t[2] = t12;
+        c.p[0] = m20, c.p[1] = m12, c.n[0] = n20, c.n[1] = n12, c.t[0] = t20, c.t[1] = t12;
+        m.p[0] = m01, m.p[1] = m12, m.p[2] = m20, m.n[0] = n01, m.n[1] = n12, m.n[2] = n20, m.t[0] = t01, m.t[1] = t12, m.t[2] = t20;
+        out.push_back( a );
+        out.push_back( b );
+        out.push_back( c );
+        out.push_back( m );
+    }
+    tris.swap( out );
+}
+
+} // namespace
+
+void addObjectsFromFileEx( const char* filename, Scene* scene, size_t default_mat, Transform& transform, float prescale, int subdivisions ) {
+    ObjData d;
+    parse_obj( filename, d );
+    std::vector<Tri> tris;
+    tris.reserve( d.face_mtl.size() );
+    for ( size_t f = 0; f < d.face_mtl.size(); f++ ) {
+        Tri t {};
+        t.has_n = !d.vn.empty();
+        t.mtl   = d.face_mtl[f];
+        for ( int k = 0; k < 3; k++ ) {
+            const ObjData::Corner& c = d.corners[3 * f + k];
+            t.p[k] = vec3( d.v[3 * c.v] * prescale, d.v[3 * c.v + 1] * prescale, d.v[3 * c.v + 2] * prescale );
+            if ( t.has_n && c.vn >= 0 ) t.n[k] = vec3( d.vn[3 * c.vn], d.vn[3 * c.vn + 1], d.vn[3 * c.vn + 2] );
+            if ( !d.vt.empty() && c.vt >= 0 ) t.t[k] = vec2 { d.vt[2 * c.vt], d.vt[2 * c.vt + 1] };
+        }
+        tris.push_back( t );
+    }
+    for ( int s = 0; s < subdivisions; s++ )
+        subdivide_once( tris );
+
+    // example_scenes.cpp:34-151
+    for ( const Tri& t : tris ) {
+        vec3 v0 = t.p[0], v1 = t.p[1], v2 = t.p[2];
+        vec3 normals[3] = { t.n[0], t.n[1], t.n[2] };
+        vec2 textures[3] = { t.t[0], t.t[1], t.t[2] };
+        vec3 n;
+        if ( !t.has_n ) {
+            vec3 v2v0  = v2 - v0;
+            vec3 v1v0  = v1 - v0;
+            n          = normalize( cross( v1v0, v2v0 ) );
+            normals[0] = normals[1] = normals[2] = n;
+        }
+        else { n = normalize( normals[0] + normals[1] + normals[2] ); }
+
+        if ( !d.mtls.empty() ) {
+            const MtlRec& mr = d.mtls[t.mtl >= 0 ? t.mtl : 0];
+            auto& mat        = scene->CreateMaterial( MaterialModel::COOK_TORRANCE );
+            mat.m_IOR        = mr.Ni;
+            mat.m_roughness  = 1.f;
+            mat.m_metalness  = 0.0;
+            mat.m_albedo     = color3( mr.Kd[0], mr.Kd[1], mr.Kd[2] );
+            if ( mr.Ke[0] != 0 || mr.Ke[1] != 0 || mr.Ke[2] != 0 ) {
+                mat.m_emission = color3( mr.Ke[0], mr.Ke[1], mr.Ke[2] );
+                auto lightObj  = initSmoothTriangle( v0, v1, v2, n, textures, normals[0], normals[1], normals[2], transform, mat.m_UID );
+                addLight( scene, new ShapeLight( vec3( 0.f ), mat.m_emission, lightObj ) );
+            }
+            if ( mr.Ks[0] == 1 && mr.Ks[1] == 1 && mr.Ks[2] == 1 ) {
+                mat.m_MatType   = SPECULAR;
+                mat.m_metalness = 1.0;
+                mat.m_roughness = 0.002;
+            }
+            addObject( scene, initSmoothTriangle( v0, v1, v2, n, textures, normals[0], normals[1], normals[2], transform, mat.m_UID ) );
+        }
+        else {
+            addObject( scene, initSmoothTriangle( v0, v1, v2, n, textures, normals[0], normals[1], normals[2], transform, (int)default_mat ) );
+        }
+    }
+}
+
+void addObjectsFromFile( const char* filename, Scene* scene, Material& default_mat, Transform& transform ) {
+    addObjectsFromFileEx( filename, scene, default_mat.m_UID, transform, 1.f, 0 );
+}
+
+bool savePPM( const char* filename, const float* rgb, uint32_t w, uint32_t h ) {
+    FILE* f = std::fopen( filename, "wb" );
+    if ( !f ) return false;
+    std::fprintf( f, "P6\n%u %u\n255\n", w, h );
+    std::vector<unsigned char> row( (size_t)w * 3 );
+    for ( uint32_t y = 0; y < h; y++ ) {
+        for ( uint32_t i = 0; i < w * 3; i++ ) {
+            int c  = (int)( 255.f * rgb[(size_t)y * w * 3 + i] ); // ivec3(255.f * c), clamp 0..255
+            row[i] = (unsigned char)( c < 0 ? 0 : ( c > 255 ? 255 : c ) );
+        }
+        std::fwrite( row.data(), 1, row.size(), f );
+    }
+    std::fclose( f );
+    return true;
+}
+
+} // namespace mrt

@@ -1,0 +1,370 @@
+// libmrt_hip.so -- the C-ABI of include/mrt.h on one MI355X (gfx950).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.py).
+// -ffp-contract=off is part of the contract, not a tuning flag: hit ids are bit-identical to the
+// CPU reference only if no multiply-add is fused.
+#include "../../include/mrt.h"
+#include "device_render.hpp"
+#include "device_trace.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+
+mrt_status fail( mrt_status st, const std::string& msg ) {
+    g_err = msg;
+    return st;
+}
+
+#define HIP_TRY( expr )                                                                                        \
+    do {                                                                                                       \
+        hipError_t e_ = ( expr );                                                                              \
+        if ( e_ != hipSuccess )                                                                                \
+            return fail( e_ == hipErrorOutOfMemory ? MRT_ERR_NOMEM : MRT_ERR_DEVICE,                            \
+                         std::string( #expr ) + ": " + hipGetErrorString( e_ ) );                             \
+    } while ( 0 )
+
+template <typename T>
+struct DevBuf {
+    T* p     = nullptr;
+    size_t n = 0;
+    hipError_t alloc( size_t count ) {
+        release();
+        n = count;
+        if ( count == 0 ) return hipSuccess;
+        return hipMalloc( (void**)&p, count * sizeof( T ) );
+    }
+    hipError_t upload( const std::vector<T>& v ) {
+        hipError_t e = alloc( v.size() );
+        if ( e != hipSuccess || v.empty() ) return e;
+        return hipMemcpy( p, v.data(), v.size() * sizeof( T ), hipMemcpyHostToDevice );
+    }
+    void release() {
+        if ( p ) (void)hipFree( p );
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// scene
+// ------------------------------------------------------------------------------------------------
+struct mrt_scene {
+    int device = 0;
+    DevBuf<uint2> nodes;
+    DevBuf<uint32_t> refs;
+    DevBuf<float4> prims;
+    DevBuf<DXf> xforms;
+    DevBuf<uint32_t> out_of_tree;
+    // shading tables
+    DevBuf<float> shade_n;  // [n][9]
+    DevBuf<float> shade_uv; // [n][6]
+    DevBuf<DMaterial> materials;
+    DevBuf<DTexture> textures;
+    DevBuf<float> texels;
+    DevBuf<DLight> lights;
+    DevBuf<float> light_cdf;
+    DevBuf<float> env_rgb;
+    DevBuf<float> env_func_int; // per-row integrals of the Distribution2D (funcInt of each conditional)
+    DTrace trace {};
+    DShade shade {};
+    RenderWorkspace ws;
+    uint64_t* d_stats = nullptr; // 8 x u64 scratch for counters
+    uint32_t tree_depth = 0;
+    ~mrt_scene() {
+        if ( d_stats ) (void)hipFree( d_stats );
+    }
+};
+
+namespace {
+
+// Walks the flattened tree on the host: every index must be in range, children must be stored
+// after their parent (which also rules out cycles), and the depth must fit the traversal stack.
+mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out ) {
+    *depth_out = 0;
+    if ( d->n_nodes == 0 ) return MRT_OK;
+    if ( !d->nodes ) return fail( MRT_ERR_INVALID, "nodes is NULL" );
+    if ( d->n_refs && !d->refs ) return fail( MRT_ERR_INVALID, "refs is NULL" );
+    std::vector<std::pair<uint32_t, uint32_t>> stack;
+    stack.emplace_back( 0u, 0u );
+    uint64_t visited = 0;
+    while ( !stack.empty() ) {
+        auto [node, depth] = stack.back();
+        stack.pop_back();
+        visited++;
+        if ( depth > *depth_out ) *depth_out = depth;
+        const mrt_kdnode& n = d->nodes[node];
+        if ( ( n.w1 & 3u ) == 3u ) {
+            uint64_t off = n.w0, cnt = n.w1 >> 2;
+            if ( off + cnt > d->n_refs ) return fail( MRT_ERR_INVALID, "leaf reference range out of bounds" );
+            for ( uint64_t i = 0; i < cnt; i++ ) {
+                uint32_t obj = d->refs[off + i];
+                if ( obj >= d->n_objects ) return fail( MRT_ERR_INVALID, "leaf references an object out of range" );
+                if ( d->obj_kind[obj] == MRT_PLANE ) return fail( MRT_ERR_INVALID, "a plane must not be inside the tree" );
+            }
+            continue;
+        }
+        uint32_t left = n.w1 >> 2;
+        if ( left <= node || (uint64_t)left + 1 >= d->n_nodes ) return fail( MRT_ERR_INVALID, "child index out of range or not after its parent" );
+        stack.emplace_back( left, depth + 1 );
+        stack.emplace_back( left + 1, depth + 1 );
+    }
+    if ( visited > d->n_nodes ) return fail( MRT_ERR_INVALID, "tree visits more nodes than it has" );
+    if ( *depth_out + 2 > MRT_STACK_MAX ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree deeper than the traversal stack (" + std::to_string( *depth_out ) + ")" );
+    return MRT_OK;
+}
+
+} // namespace
+
+static mrt_status upload_shading( const mrt_scene_desc* d, mrt_scene* s ); // render_host.inc
+
+extern "C" {
+
+const char* mrt_last_error( void ) {
+    return g_err.c_str();
+}
+int32_t mrt_version( void ) {
+    return 1;
+}
+
+mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** out ) {
+    if ( !d || !out ) return fail( MRT_ERR_INVALID, "NULL argument" );
+    *out = nullptr;
+    if ( d->struct_size != sizeof( mrt_scene_desc ) ) return fail( MRT_ERR_INVALID, "mrt_scene_desc.struct_size mismatch" );
+    if ( d->n_objects && ( !d->obj_kind || !d->obj_material || !d->obj_transform || !d->tri_p || !d->tri_n || !d->tri_uv || !d->sphere ) )
+        return fail( MRT_ERR_INVALID, "object arrays are NULL" );
+    if ( d->n_transforms == 0 || !d->transforms ) return fail( MRT_ERR_INVALID, "at least one transform (the identity, index 0) is required" );
+    if ( d->n_materials == 0 || !d->materials ) return fail( MRT_ERR_INVALID, "at least one material is required" );
+    if ( d->n_objects >= ( 1u << 29 ) || d->n_transforms >= ( 1u << 28 ) ) return fail( MRT_ERR_UNSUPPORTED, "too many objects or transforms" );
+    {
+        static const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+        static const float zero[3]  = { 0, 0, 0 };
+        const mrt_transform& t0     = d->transforms[0];
+        if ( std::memcmp( t0.m, ident, 36 ) || std::memcmp( t0.inv, ident, 36 ) || std::memcmp( t0.t, zero, 12 ) )
+            return fail( MRT_ERR_INVALID, "transform 0 must be the identity" );
+    }
+    uint32_t depth = 0;
+    mrt_status vs  = validate_tree( d, &depth );
+    if ( vs != MRT_OK ) return vs;
+    for ( uint32_t i = 0; i < d->n_out_of_tree; i++ )
+        if ( d->out_of_tree[i] >= d->n_objects ) return fail( MRT_ERR_INVALID, "out_of_tree index out of range" );
+
+    int n_dev = 0;
+    HIP_TRY( hipGetDeviceCount( &n_dev ) );
+    if ( device < 0 || device >= n_dev ) return fail( MRT_ERR_DEVICE, "no such HIP device" );
+    HIP_TRY( hipSetDevice( device ) );
+
+    std::vector<float4> prims( 3 * (size_t)d->n_objects );
+    for ( uint32_t i = 0; i < d->n_objects; i++ ) {
+        uint32_t kind = d->obj_kind[i], mat = d->obj_material[i], xf = d->obj_transform[i];
+        if ( mat >= d->n_materials ) return fail( MRT_ERR_INVALID, "object material out of range" );
+        if ( xf >= d->n_transforms ) return fail( MRT_ERR_INVALID, "object transform out of range" );
+        uint32_t k;
+        if ( kind == MRT_TRIANGLE ) k = MRT_PRIM_TRI;
+        else if ( kind == MRT_SPHERE ) k = MRT_PRIM_SPHERE;
+        else if ( kind == MRT_PLANE ) k = MRT_PRIM_PLANE;
+        else return fail( MRT_ERR_UNSUPPORTED, "unsupported object kind" );
+        const float* e = d->materials[mat].emission;
+        // kdtree.cpp:533-534: a shadow ray ignores a hit iff all three emission components are non-zero-tested
+        uint32_t emissive = !( e[0] == 0.f && e[1] == 0.f && e[2] == 0.f );
+        uint32_t flags    = k | ( emissive ? MRT_PRIM_EMISSIVE : 0u ) | ( xf << 3 );
+        const float* p    = d->tri_p + 9 * (size_t)i;
+        float fl, fm;
+        std::memcpy( &fl, &flags, 4 );
+        std::memcpy( &fm, &mat, 4 );
+        // e1 = p2 - p1, e2 = p3 - p1: one fp32 subtraction each, as triangle.cpp:9-10 does per test
+        float e1[3] = { p[3] - p[0], p[4] - p[1], p[5] - p[2] };
+        float e2[3] = { p[6] - p[0], p[7] - p[1], p[8] - p[2] };
+        prims[3 * (size_t)i]     = make_float4( p[0], p[1], p[2], fl );
+        prims[3 * (size_t)i + 1] = make_float4( e1[0], e1[1], e1[2], e2[0] );
+        prims[3 * (size_t)i + 2] = make_float4( e2[1], e2[2], fm, 0.f );
+    }
+    std::vector<DXf> xforms( d->n_transforms );
+    for ( uint32_t i = 0; i < d->n_transforms; i++ ) {
+        std::memcpy( xforms[i].inv, d->transforms[i].inv, 36 );
+        std::memcpy( xforms[i].t, d->transforms[i].t, 12 );
+        std::memcpy( xforms[i].m, d->transforms[i].m, 36 );
+        xforms[i].pad[0] = xforms[i].pad[1] = xforms[i].pad[2] = 0.f;
+    }
+    std::vector<uint2> nodes( d->n_nodes );
+    for ( uint32_t i = 0; i < d->n_nodes; i++ )
+        nodes[i] = make_uint2( d->nodes[i].w0, d->nodes[i].w1 );
+
+    std::unique_ptr<mrt_scene> s( new mrt_scene );
+    s->device     = device;
+    s->tree_depth = depth;
+    HIP_TRY( s->nodes.upload( nodes ) );
+    HIP_TRY( s->refs.upload( std::vector<uint32_t>( d->refs, d->refs + d->n_refs ) ) );
+    HIP_TRY( s->prims.upload( prims ) );
+    HIP_TRY( s->xforms.upload( xforms ) );
+    HIP_TRY( s->out_of_tree.upload( std::vector<uint32_t>( d->out_of_tree, d->out_of_tree + d->n_out_of_tree ) ) );
+    HIP_TRY( hipMalloc( (void**)&s->d_stats, 8 * sizeof( uint64_t ) ) );
+
+    DTrace& t     = s->trace;
+    t.nodes       = s->nodes.p;
+    t.refs        = s->refs.p;
+    t.prims       = s->prims.p;
+    t.xforms      = s->xforms.p;
+    t.out_of_tree = s->out_of_tree.p;
+    t.n_nodes     = d->n_nodes;
+    t.n_out       = d->n_out_of_tree;
+    for ( int k = 0; k < 3; k++ ) {
+        t.root_min[k] = d->root_min[k];
+        t.root_max[k] = d->root_max[k];
+    }
+
+    mrt_status ss = upload_shading( d, s.get() );
+    if ( ss != MRT_OK ) return ss;
+    *out = s.release();
+    return MRT_OK;
+}
+
+void mrt_scene_destroy( mrt_scene* scene ) {
+    if ( !scene ) return;
+    (void)hipSetDevice( scene->device );
+    delete scene;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// mrt_intersect
+// ------------------------------------------------------------------------------------------------
+template <bool ANY, bool STATS>
+__global__ void __launch_bounds__( 256 ) extend_batch_kernel( DTrace s,
+                                                              uint64_t n,
+                                                              const float* __restrict__ ox,
+                                                              const float* __restrict__ oy,
+                                                              const float* __restrict__ oz,
+                                                              const float* __restrict__ dx,
+                                                              const float* __restrict__ dy,
+                                                              const float* __restrict__ dz,
+                                                              const float* __restrict__ tmin,
+                                                              const float* __restrict__ tmax,
+                                                              int32_t* __restrict__ prim,
+                                                              float* __restrict__ t,
+                                                              float* __restrict__ u,
+                                                              float* __restrict__ v,
+                                                              unsigned long long* __restrict__ stats ) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    DStats st { 0, 0, 0, 0 };
+    if ( i < n ) {
+        DHit h;
+        trace_ray<ANY, STATS>( s, mk3( ox[i], oy[i], oz[i] ), mk3( dx[i], dy[i], dz[i] ), tmin[i], tmax[i], h, st );
+        prim[i] = h.prim;
+        t[i]    = h.t;
+        u[i]    = h.u;
+        v[i]    = h.v;
+    }
+    if ( STATS ) {
+        // one atomic per wave and counter
+        unsigned long long vals[4] = { st.inner, st.leaves, st.refs, st.tests };
+        for ( int k = 0; k < 4; k++ ) {
+            unsigned long long x = vals[k];
+            for ( int off = 32; off > 0; off >>= 1 )
+                x += __shfl_down( x, off );
+            if ( ( threadIdx.x & 63 ) == 0 ) atomicAdd( &stats[k], x );
+        }
+    }
+}
+
+extern "C" mrt_status mrt_intersect( mrt_scene* sc,
+                                     uint64_t n,
+                                     const mrt_rays* rays,
+                                     const mrt_hits* hits,
+                                     uint32_t flags,
+                                     uint32_t placement,
+                                     void* stream_,
+                                     mrt_trace_stats* stats ) {
+    if ( !sc || !rays || !hits ) return fail( MRT_ERR_INVALID, "NULL argument" );
+    if ( flags != MRT_CLOSEST_HIT && flags != MRT_ANY_HIT ) return fail( MRT_ERR_INVALID, "flags must be MRT_CLOSEST_HIT or MRT_ANY_HIT" );
+    if ( placement != MRT_BUF_HOST && placement != MRT_BUF_DEVICE ) return fail( MRT_ERR_INVALID, "bad placement" );
+    if ( n == 0 ) {
+        if ( stats ) *stats = mrt_trace_stats {};
+        return MRT_OK;
+    }
+    if ( n > ( 1ull << 31 ) ) return fail( MRT_ERR_UNSUPPORTED, "batch larger than 2^31 rays" );
+    const float* in[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmin, rays->tmax };
+    for ( const float* p : in )
+        if ( !p ) return fail( MRT_ERR_INVALID, "NULL ray array" );
+    if ( !hits->prim || !hits->t || !hits->u || !hits->v ) return fail( MRT_ERR_INVALID, "NULL hit array" );
+    HIP_TRY( hipSetDevice( sc->device ) );
+    hipStream_t stream = (hipStream_t)stream_;
+
+    DevBuf<float> d_in, d_outf;
+    DevBuf<int32_t> d_prim;
+    const float* din[8];
+    int32_t* dprim;
+    float *dt, *du, *dv;
+    if ( placement == MRT_BUF_HOST ) {
+        HIP_TRY( d_in.alloc( 8 * n ) );
+        HIP_TRY( d_outf.alloc( 3 * n ) );
+        HIP_TRY( d_prim.alloc( n ) );
+        for ( int k = 0; k < 8; k++ ) {
+            HIP_TRY( hipMemcpyAsync( d_in.p + k * n, in[k], n * sizeof( float ), hipMemcpyHostToDevice, stream ) );
+            din[k] = d_in.p + k * n;
+        }
+        dprim = d_prim.p;
+        dt    = d_outf.p;
+        du    = d_outf.p + n;
+        dv    = d_outf.p + 2 * n;
+    }
+    else {
+        for ( int k = 0; k < 8; k++ )
+            din[k] = in[k];
+        dprim = hits->prim;
+        dt    = hits->t;
+        du    = hits->u;
+        dv    = hits->v;
+    }
+    if ( stats ) HIP_TRY( hipMemsetAsync( sc->d_stats, 0, 8 * sizeof( uint64_t ), stream ) );
+    const dim3 block( 256 ), grid( (unsigned)( ( n + 255 ) / 256 ) );
+    unsigned long long* ds = (unsigned long long*)sc->d_stats;
+#define LAUNCH( A, S ) \
+    hipLaunchKernelGGL( ( extend_batch_kernel<A, S> ), grid, block, 0, stream, sc->trace, n, din[0], din[1], din[2], din[3], din[4], din[5], din[6], din[7], dprim, dt, du, dv, ds )
+    if ( flags == MRT_ANY_HIT ) {
+        if ( stats ) LAUNCH( true, true );
+        else LAUNCH( true, false );
+    }
+    else {
+        if ( stats ) LAUNCH( false, true );
+        else LAUNCH( false, false );
+    }
+#undef LAUNCH
+    HIP_TRY( hipGetLastError() );
+    if ( placement == MRT_BUF_HOST ) {
+        HIP_TRY( hipMemcpyAsync( hits->prim, dprim, n * sizeof( int32_t ), hipMemcpyDeviceToHost, stream ) );
+        HIP_TRY( hipMemcpyAsync( hits->t, dt, n * sizeof( float ), hipMemcpyDeviceToHost, stream ) );
+        HIP_TRY( hipMemcpyAsync( hits->u, du, n * sizeof( float ), hipMemcpyDeviceToHost, stream ) );
+        HIP_TRY( hipMemcpyAsync( hits->v, dv, n * sizeof( float ), hipMemcpyDeviceToHost, stream ) );
+    }
+    if ( stats ) {
+        uint64_t h[8];
+        HIP_TRY( hipMemcpyAsync( h, sc->d_stats, sizeof( h ), hipMemcpyDeviceToHost, stream ) );
+        HIP_TRY( hipStreamSynchronize( stream ) );
+        stats->inner      = h[0];
+        stats->leaves     = h[1];
+        stats->refs       = h[2];
+        stats->prim_tests = h[3];
+    }
+    else if ( placement == MRT_BUF_HOST ) { HIP_TRY( hipStreamSynchronize( stream ) ); }
+    return MRT_OK;
+}
+
+#include "render_host.inc"
