@@ -1,8 +1,346 @@
-// placeholder: filled in with the wavefront path-tracing kernels
+// Wavefront path tracer for gfx950: generate -> [extend -> shade -> connect]* -> accumulate.
+//
+// It computes what CPURenderer::run does for one camera sample (rendering/CPURenderer.cpp:46-62):
+// camera sample, SimpleCamera::get_ray, then Pathtracer::trace_ray (integrator.cpp:128-211) with
+// directIllumination (integrator.cpp:69-120).  One path = one camera sample; all per-path state is
+// struct-of-arrays in HBM, indexed by the path id
+//     id = sample_local * n_pixels + pixel_local
+// so that the 64 lanes of a wave hold 64 neighbouring pixels of one sample index (coherent
+// primary rays, coalesced state access).  Work lists are queues of path ids; the kernels are
+//   generate        camera sample + primary ray for every id
+//   extend          closest-hit traversal of the continuation ray of every live path
+//   shade           everything of one loop iteration of trace_ray that needs no further ray:
+//                   emission at depth 0, light choice, light sample + BSDF eval, BSDF sample for
+//                   MIS, BSDF sample for the continuation, throughput update; emits one shadow
+//                   ray and (when the light pdf is non-zero) one MIS ray, and queues survivors
+//   connect_shadow  any-hit traversal of the shadow rays; an occluded ray cancels its contribution
+//   connect_mis     closest-hit traversal of the MIS rays; adds bsdf * Li * w / pdf
+//   accumulate      folds the last pending direct-lighting term of every path and adds the
+//                   per-sample radiances of a pixel, in sample order, to the image sum
+// Dead paths are retired by wave ballot + one atomic per wave when the next queue is written.
+//
+// Order of the float additions into a path's radiance follows the reference: depth-0 emission,
+// then per bounce (throughput * DI) / lightPdf with DI = (0 + light term) + bsdf term, finally
+// throughput * Le on a miss.  A bounce's DI is complete only after both connect kernels, so it is
+// kept pending and folded in by the next shade of the path or by accumulate.
 #pragma once
-#include "device_trace.hpp"
-struct DMaterial { float albedo[3]; float emission[3]; float ior, roughness, metalness; int32_t type, texture; };
-struct DTexture { int32_t kind; uint32_t w, h; uint32_t pad; uint64_t offset; float even[3], odd[3]; DXf xf; };
-struct DLight { int32_t kind; float color[3]; int32_t shape_kind; uint32_t xf; float p[9]; float n[9]; float sphere[4]; };
-struct DShade { int dummy; };
-struct RenderWorkspace { int dummy; };
+#include "device_shading.hpp"
+
+struct PathState {
+    // continuation ray (tmin = 0; tmax = 1e5 for camera rays, 1e4 afterwards)
+    float *ox, *oy, *oz, *dx, *dy, *dz;
+    // closest hit of the continuation ray
+    int32_t* h_prim;
+    float *h_t, *h_u, *h_v;
+    uint32_t* h_outside;
+    // path
+    float *tpx, *tpy, *tpz; // throughput
+    float *Lx, *Ly, *Lz;    // radiance so far
+    uint64_t *rng_state, *rng_inc;
+    // pending direct lighting of the last shaded bounce: L += (ptp * di) / pick_pdf
+    float *ptx, *pty, *ptz, *dix, *diy, *diz, *pick_pdf;
+    uint32_t* pending;
+    // shadow ray + its contribution (already in di; cancelled if occluded)
+    float *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax;
+    // MIS ray + factors of its contribution
+    float *mox, *moy, *moz, *mdx, *mdy, *mdz;
+    float *mbx, *mby, *mbz, *mw, *mpdf;
+    uint32_t* mlight;
+};
+#define MRT_PATH_WORDS 53
+
+struct PassInfo {
+    uint32_t width;
+    uint32_t row_begin, n_rows;      // pixel_local = (y - row_begin) * width + x
+    uint32_t sample_begin, n_samples;
+    uint32_t spp_x, spp_y;
+    uint32_t seed;
+    uint32_t n_pixels;               // n_rows * width
+    uint32_t n_paths;                // n_pixels * n_samples
+    uint32_t max_depth;
+};
+
+struct Queues {
+    uint32_t* cur;     // live paths of this bounce
+    uint32_t* next;    // survivors
+    uint32_t* shadow;  // paths with a shadow ray
+    uint32_t* mis;     // paths with a MIS ray
+    uint32_t* counts;  // [0] next, [1] shadow, [2] mis
+};
+
+struct RenderCounters {
+    unsigned long long* c; // [0] closest rays, [1] any-hit rays
+};
+
+// Appends `id` to a queue for the lanes where `take` holds: one atomic per wave.
+MRT_DEV void queue_push( uint32_t* queue, uint32_t* counter, bool take, uint32_t id ) {
+    const unsigned long long mask = __ballot( take );
+    if ( mask == 0 ) return;
+    const uint32_t lane   = __lane_id();
+    const uint32_t leader = (uint32_t)__ffsll( (long long)mask ) - 1;
+    uint32_t base         = 0;
+    if ( lane == leader ) base = atomicAdd( counter, (uint32_t)__popcll( mask ) );
+    base = __shfl( base, leader );
+    if ( take ) queue[base + __popcll( mask & ( ( 1ull << lane ) - 1 ) )] = id;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__( 256 ) generate_kernel( PathState ps, PassInfo pi, DCamera cam ) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( id >= pi.n_paths ) return;
+    const uint32_t s_local = id / pi.n_pixels, p_local = id - s_local * pi.n_pixels;
+    const uint32_t y = pi.row_begin + p_local / pi.width, x = p_local % pi.width;
+    const uint32_t pixel  = y * pi.width + x;
+    const uint32_t sample = pi.sample_begin + s_local;
+    const uint64_t key    = pixel_key( pi.seed, pixel );
+    Pcg32 rng;
+    pcg_set_sequence( rng, sample_sequence( key, sample ) );
+    // Sampler::GetCameraSample (sampler.cpp:43-49): 2D dim 0, 1D dim 0 (time, unused), 2D dim 1
+    V2 jit  = strat2d( key, 0, sample, pi.spp_x, pi.spp_y );
+    V2 lens = strat2d( key, 1, sample, pi.spp_x, pi.spp_y );
+    V3 o, d;
+    camera_ray( cam, (float)x + jit.x, (float)y + jit.y, lens.x, lens.y, o, d );
+    ps.ox[id] = o.x, ps.oy[id] = o.y, ps.oz[id] = o.z;
+    ps.dx[id] = d.x, ps.dy[id] = d.y, ps.dz[id] = d.z;
+    ps.tpx[id] = ps.tpy[id] = ps.tpz[id] = 1.f;
+    ps.Lx[id] = ps.Ly[id] = ps.Lz[id] = 0.f;
+    ps.rng_state[id] = rng.state;
+    ps.rng_inc[id]   = rng.inc;
+    ps.pending[id]   = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// extend: closest hit of the continuation rays.  `queue` == nullptr means the identity queue.
+__global__ void __launch_bounds__( 256 ) extend_kernel( DTrace tr, PathState ps, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_max, float tmax ) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = n_ptr ? *n_ptr : n_max;
+    if ( i >= n ) return;
+    const uint32_t id = queue ? queue[i] : i;
+    DHit h;
+    DStats st;
+    trace_ray<false, false>( tr, mk3( ps.ox[id], ps.oy[id], ps.oz[id] ), mk3( ps.dx[id], ps.dy[id], ps.dz[id] ), 0.f, tmax, h, st );
+    ps.h_prim[id]    = h.prim;
+    ps.h_t[id]       = h.t;
+    ps.h_u[id]       = h.u;
+    ps.h_v[id]       = h.v;
+    ps.h_outside[id] = h.outside;
+}
+
+// ------------------------------------------------------------------------------------------------
+MRT_DEV void fold_pending( PathState& ps, uint32_t id, V3& L ) {
+    if ( !ps.pending[id] ) return;
+    // ret += throughput * directIllumination(...) / lightPdf   (integrator.cpp:169-177)
+    V3 tp = mk3( ps.ptx[id], ps.pty[id], ps.ptz[id] ), di = mk3( ps.dix[id], ps.diy[id], ps.diz[id] );
+    L     = L + ( tp * di ) / ps.pick_pdf[id];
+    ps.pending[id] = 0;
+}
+
+__global__ void __launch_bounds__( 256 ) shade_kernel( DTrace tr, DShade sh, PathState ps, PassInfo pi, Queues q, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t depth ) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = n_ptr ? *n_ptr : n_max;
+    bool alive = false, has_shadow = false, has_mis = false;
+    uint32_t id = 0;
+    if ( i < n ) {
+        id = queue ? queue[i] : i;
+        V3 L = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
+        fold_pending( ps, id, L );
+        V3 tp = mk3( ps.tpx[id], ps.tpy[id], ps.tpz[id] );
+        V3 ro = mk3( ps.ox[id], ps.oy[id], ps.oz[id] ), rd = mk3( ps.dx[id], ps.dy[id], ps.dz[id] );
+        DHit h;
+        h.prim = ps.h_prim[id];
+        if ( h.prim < 0 ) {
+            // integrator.cpp:195-198
+            if ( sh.env_light >= 0 ) L = L + tp * ibl_Le( sh, rd );
+        }
+        else {
+            h.t       = ps.h_t[id];
+            h.u       = ps.h_u[id];
+            h.v       = ps.h_v[id];
+            h.outside = ps.h_outside[id];
+            Surf sf   = surface_from_hit( tr, sh, ro, rd, h );
+            const DMaterial mat = sh.materials[sf.material];
+            Pcg32 rng;
+            rng.state = ps.rng_state[id];
+            rng.inc   = ps.rng_inc[id];
+            const uint32_t s_local = id / pi.n_pixels, p_local = id - s_local * pi.n_pixels;
+            const uint32_t pixel  = ( pi.row_begin + p_local / pi.width ) * pi.width + p_local % pi.width;
+            const uint32_t sample = pi.sample_begin + s_local;
+            const uint64_t key    = pixel_key( pi.seed, pixel );
+
+            // integrator.cpp:147-150
+            if ( !is_black( ld3( mat.emission ) ) && depth == 0 ) {
+                V3 col = dot3( sf.normal, -rd ) > 0.f ? ld3( sh.light0_color ) : mk3( 0.f );
+                L      = L + tp * col;
+            }
+            // integrator.cpp:152-178
+            if ( sh.n_lights > 0 ) {
+                // sampler dimensions consumed so far: 1D 1 + depth, 2D 2 + 3*depth
+                const uint32_t d1 = 1 + depth, d2 = 2 + 3 * depth;
+                float u1 = d1 < 8 ? strat1d( key, d1, sample, pi.spp_x * pi.spp_y ) : pcg_float( rng );
+                float lightPickPdf;
+                int li = sample_discrete( sh.light_cdf, (int)sh.n_lights + 1, sh.light_func_int, u1, lightPickPdf );
+                if ( lightPickPdf > 0 ) {
+                    V2 uLight;
+                    if ( d2 < 8 ) uLight = strat2d( key, d2, sample, pi.spp_x, pi.spp_y );
+                    else {
+                        uLight.x = pcg_float( rng );
+                        uLight.y = pcg_float( rng );
+                    }
+                    // ---- directIllumination (integrator.cpp:69-120)
+                    const DLight& light = sh.lights[li];
+                    V3 di               = mk3( 0.f );
+                    V3 wi               = mk3( 0.f );
+                    float lightPdf = 0, scatteringPdf = 0;
+                    V3 Li;
+                    V3 s_o, s_d;
+                    float s_tmax;
+                    if ( light.kind == 0 ) { // ShapeLight::sample_Li (Light.cpp:251-271)
+                        ShapePoint pShape = light_shape_sample( tr, light, sf, uLight, lightPdf );
+                        wi                = normalize3( pShape.position - sf.position );
+                        s_o               = sf.position + ( MRT_ACNE_EPS * sf.normal );
+                        s_d               = wi;
+                        s_tmax            = length3( sf.position - pShape.position ) * 0.99f;
+                        Li                = dot3( pShape.normal, -wi ) > 0.f ? ld3( light.color ) : mk3( 0.f );
+                    }
+                    else { // IBL::sample_Li (Light.cpp:277-315)
+                        V3 normal = sf.outside ? sf.normal : -sf.normal;
+                        wi        = normalize3( random_dir( normal, rng ) );
+                        lightPdf  = fmax_glm( dot3( normal, wi ), 0.f ) / MRT_PI;
+                        s_o       = sf.position + wi * MRT_ACNE_EPS;
+                        s_d       = wi;
+                        s_tmax    = 10000.f;
+                        Li        = ibl_sample_texel( sh, wi );
+                    }
+                    // the reference always traces the shadow ray inside sample_Li; its result is
+                    // only read when the contribution below is non-black, so it is traced only then
+                    if ( lightPdf > 0 && !is_black( Li ) ) {
+                        V3 normal = sf.outside ? sf.normal : -sf.normal;
+                        V3 bsdf   = material_eval( sh, mat, rd, sf, wi, scatteringPdf ) * fmax_glm( dot3( normal, wi ), 0.f );
+                        if ( !is_black( bsdf ) ) {
+                            float weight = power_heuristic( lightPdf, scatteringPdf );
+                            di           = di + bsdf * Li * weight / lightPdf;
+                            has_shadow   = true;
+                            ps.sox[id] = s_o.x, ps.soy[id] = s_o.y, ps.soz[id] = s_o.z;
+                            ps.sdx[id] = s_d.x, ps.sdy[id] = s_d.y, ps.sdz[id] = s_d.z;
+                            ps.stmax[id] = s_tmax;
+                        }
+                    }
+                    V3 bsdf = material_sample( sh, mat, rd, sf, rng, wi, scatteringPdf ) * fmax_glm( dot3( sf.normal, wi ), 0.f );
+                    if ( !is_black( bsdf ) && scatteringPdf > 0 ) {
+                        float lp = light.kind == 0 ? light_shape_pdf( tr, light, sf, wi ) : ibl_pdf_Li( sh, wi );
+                        if ( lp != 0 ) {
+                            float weight = power_heuristic( scatteringPdf, lp );
+                            V3 m_o       = sf.position + ( wi * MRT_ACNE_EPS );
+                            V3 m_d       = normalize3( wi );
+                            has_mis      = true;
+                            ps.mox[id] = m_o.x, ps.moy[id] = m_o.y, ps.moz[id] = m_o.z;
+                            ps.mdx[id] = m_d.x, ps.mdy[id] = m_d.y, ps.mdz[id] = m_d.z;
+                            ps.mbx[id] = bsdf.x, ps.mby[id] = bsdf.y, ps.mbz[id] = bsdf.z;
+                            ps.mw[id]     = weight;
+                            ps.mpdf[id]   = scatteringPdf;
+                            ps.mlight[id] = (uint32_t)li;
+                        }
+                    }
+                    ps.ptx[id] = tp.x, ps.pty[id] = tp.y, ps.ptz[id] = tp.z;
+                    ps.dix[id] = di.x, ps.diy[id] = di.y, ps.diz[id] = di.z;
+                    ps.pick_pdf[id] = lightPickPdf;
+                    ps.pending[id]  = 1;
+                }
+            }
+            // integrator.cpp:180-193
+            float pdf = 0.f;
+            V3 wi     = mk3( 0.f );
+            V3 bsdf   = material_sample( sh, mat, rd, sf, rng, wi, pdf );
+            wi        = normalize3( wi );
+            if ( !( is_black( bsdf ) || pdf == 0.f ) ) {
+                if ( mat.type != 2 ) tp = tp * ( bsdf * fabsf( dot3( wi, sf.normal ) ) / pdf );
+                V3 no = sf.position + MRT_ACNE_EPS * wi;
+                ps.ox[id] = no.x, ps.oy[id] = no.y, ps.oz[id] = no.z;
+                ps.dx[id] = wi.x, ps.dy[id] = wi.y, ps.dz[id] = wi.z;
+                ps.tpx[id] = tp.x, ps.tpy[id] = tp.y, ps.tpz[id] = tp.z;
+                alive = depth < pi.max_depth; // integrator.cpp:201
+            }
+            ps.rng_state[id] = rng.state;
+        }
+        ps.Lx[id] = L.x, ps.Ly[id] = L.y, ps.Lz[id] = L.z;
+    }
+    queue_push( q.next, q.counts + 0, alive, id );
+    queue_push( q.shadow, q.counts + 1, has_shadow, id );
+    queue_push( q.mis, q.counts + 2, has_mis, id );
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__( 256 ) connect_shadow_kernel( DTrace tr, PathState ps, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count ) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= *count ) return;
+    const uint32_t id = queue[i];
+    DHit h;
+    DStats st;
+    bool occluded = trace_ray<true, false>( tr, mk3( ps.sox[id], ps.soy[id], ps.soz[id] ), mk3( ps.sdx[id], ps.sdy[id], ps.sdz[id] ), 0.f, ps.stmax[id], h, st );
+    // integrator.cpp:88: `if (vis) Li = 0` -- the light term was the only term in DI so far
+    if ( occluded ) ps.dix[id] = ps.diy[id] = ps.diz[id] = 0.f;
+}
+
+__global__ void __launch_bounds__( 256 ) connect_mis_kernel( DTrace tr, DShade sh, PathState ps, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count ) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= *count ) return;
+    const uint32_t id = queue[i];
+    DHit h;
+    DStats st;
+    V3 o = mk3( ps.mox[id], ps.moy[id], ps.moz[id] ), d = mk3( ps.mdx[id], ps.mdy[id], ps.mdz[id] );
+    bool found = trace_ray<false, false>( tr, o, d, 0.f, 10000.f, h, st );
+    const uint32_t li = ps.mlight[id];
+    V3 Li             = mk3( 0.f );
+    if ( found ) { // integrator.cpp:108-113
+        const uint32_t flags = __float_as_uint( tr.prims[3 * (size_t)h.prim].w );
+        if ( flags & MRT_PRIM_EMISSIVE_SUM ) {
+            Surf sf = surface_from_hit( tr, sh, o, d, h );
+            // `wi` of the reference is the un-normalised sample direction; the ray direction is
+            // normalize(wi) and wi is already unit length up to rounding, the sign test is the same
+            Li = dot3( sf.normal, -d ) > 0.f ? ld3( sh.lights[li].color ) : mk3( 0.f );
+        }
+    }
+    else if ( sh.lights[li].kind == 1 ) { Li = ibl_Le( sh, d ); } // Light::Le is black for shape lights
+    if ( !is_black( Li ) ) {
+        V3 bsdf = mk3( ps.mbx[id], ps.mby[id], ps.mbz[id] );
+        V3 c    = bsdf * Li * ps.mw[id] / ps.mpdf[id];
+        ps.dix[id] += c.x;
+        ps.diy[id] += c.y;
+        ps.diz[id] += c.z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One thread per pixel of the pass: radiances of its samples are added in sample order
+// (CPURenderer.cpp:60: pixel_color += trace_ray(...)), then added to the image sum.
+__global__ void __launch_bounds__( 256 ) accumulate_kernel( PathState ps, PassInfo pi, float* __restrict__ rgb_sum ) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( p >= pi.n_pixels ) return;
+    V3 sum = mk3( 0.f );
+    for ( uint32_t s = 0; s < pi.n_samples; s++ ) {
+        const uint32_t id = s * pi.n_pixels + p;
+        V3 L              = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
+        fold_pending( ps, id, L );
+        sum = sum + L;
+    }
+    const uint32_t pixel = ( pi.row_begin + p / pi.width ) * pi.width + p % pi.width;
+    float* dst           = rgb_sum + 3 * (size_t)pixel;
+    dst[0] += sum.x;
+    dst[1] += sum.y;
+    dst[2] += sum.z;
+}
+
+// out = powf(sum / spp, 1.0f / 2.2) (CPURenderer.cpp:64-69)
+__global__ void __launch_bounds__( 256 ) resolve_kernel( const float* __restrict__ sum, float* __restrict__ out, uint64_t n, float spp ) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    out[i] = powf( sum[i] / spp, (float)( 1.0f / 2.2 ) );
+}
+
+struct RenderWorkspace {
+    float* words      = nullptr; // MRT_PATH_WORDS arrays of capacity floats (u64 arrays take two)
+    uint32_t* queues  = nullptr; // 4 queues of capacity ids
+    uint32_t* counts  = nullptr; // 4 counters
+    unsigned long long* ray_counts = nullptr;
+    uint32_t capacity = 0;
+};

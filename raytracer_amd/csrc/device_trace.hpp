@@ -27,13 +27,17 @@
 #define MRT_ACNE_EPS 1e-4f
 
 // prim record: 3 x float4
-//   q0 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane), bit 2 emissive,
-//   q1 = e1.xyz , e2.x              bits 3.. transform index (0 = identity)
-//   q2 = e2.yz  , material , 0      e1 = p2 - p1, e2 = p3 - p1 (fp32, as triangle.cpp:9-10)
+//   q0 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane),
+//   q1 = e1.xyz , e2.x              bit 2 emission != (0,0,0) component-wise (kdtree.cpp:533-534),
+//   q2 = e2.yz  , material , 0      bit 3 emission.r+g+b != 0 (isBlack, integrator.cpp:110),
+//                                   bits 4.. transform index (0 = identity)
+//   e1 = p2 - p1, e2 = p3 - p1 (fp32, as triangle.cpp:9-10)
 #define MRT_PRIM_TRI 0u
 #define MRT_PRIM_SPHERE 1u
 #define MRT_PRIM_PLANE 2u
 #define MRT_PRIM_EMISSIVE 4u
+#define MRT_PRIM_EMISSIVE_SUM 8u
+#define MRT_PRIM_XF_SHIFT 4
 
 struct DTrace {
     const uint2* nodes;
@@ -83,7 +87,7 @@ MRT_DEV bool prim_intersect( const DTrace& s, uint32_t obj, V3 wo, V3 wd, float 
     const float4 q0      = s.prims[3 * (size_t)obj];
     const uint32_t flags = __float_as_uint( q0.w );
     const uint32_t kind  = flags & 3u;
-    to_object( s, flags >> 3, wo, wd, xr );
+    to_object( s, flags >> MRT_PRIM_XF_SHIFT, wo, wd, xr );
     const V3 origin = xr.o, dir = xr.d;
     if ( kind == MRT_PRIM_TRI ) {
         const float4 q1 = s.prims[3 * (size_t)obj + 1];
@@ -123,8 +127,8 @@ MRT_DEV bool prim_intersect( const DTrace& s, uint32_t obj, V3 wo, V3 wd, float 
             if ( !( t >= tmin && t <= tmax ) ) return false;
             // the one-root branch takes its normal from the world hit point mapped back
             V3 pos         = wo + ( t * wd );
-            const DXf& xf  = s.xforms[flags >> 3];
-            V3 objectPoint = ( flags >> 3 ) == 0 ? pos : mat_mul( xf.inv, pos - mk3( xf.t[0], xf.t[1], xf.t[2] ) );
+            const DXf& xf  = s.xforms[flags >> MRT_PRIM_XF_SHIFT];
+            V3 objectPoint = ( flags >> MRT_PRIM_XF_SHIFT ) == 0 ? pos : mat_mul( xf.inv, pos - mk3( xf.t[0], xf.t[1], xf.t[2] ) );
             h.outside      = dot3( dir, objectPoint ) < 0;
         }
         else if ( delta > 0 ) {

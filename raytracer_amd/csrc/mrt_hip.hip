@@ -87,9 +87,8 @@ struct mrt_scene {
     RenderWorkspace ws;
     uint64_t* d_stats = nullptr; // 8 x u64 scratch for counters
     uint32_t tree_depth = 0;
-    ~mrt_scene() {
-        if ( d_stats ) (void)hipFree( d_stats );
-    }
+    bool has_camera     = false;
+    ~mrt_scene();
 };
 
 namespace {
@@ -133,6 +132,13 @@ mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out ) {
 } // namespace
 
 static mrt_status upload_shading( const mrt_scene_desc* d, mrt_scene* s ); // render_host.inc
+namespace {
+void free_workspace( RenderWorkspace& w );
+}
+mrt_scene::~mrt_scene() {
+    if ( d_stats ) (void)hipFree( d_stats );
+    free_workspace( ws );
+}
 
 extern "C" {
 
@@ -183,7 +189,8 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         const float* e = d->materials[mat].emission;
         // kdtree.cpp:533-534: a shadow ray ignores a hit iff all three emission components are non-zero-tested
         uint32_t emissive = !( e[0] == 0.f && e[1] == 0.f && e[2] == 0.f );
-        uint32_t flags    = k | ( emissive ? MRT_PRIM_EMISSIVE : 0u ) | ( xf << 3 );
+        uint32_t em_sum   = !( e[0] + e[1] + e[2] == 0.f );
+        uint32_t flags    = k | ( emissive ? MRT_PRIM_EMISSIVE : 0u ) | ( em_sum ? MRT_PRIM_EMISSIVE_SUM : 0u ) | ( xf << MRT_PRIM_XF_SHIFT );
         const float* p    = d->tri_p + 9 * (size_t)i;
         float fl, fm;
         std::memcpy( &fl, &flags, 4 );

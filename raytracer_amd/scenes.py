@@ -58,19 +58,19 @@ def bunny_ibl(width=1920, height=1080, glossy=False, obj="stanford-bunny.obj", p
 
 
 def small_bunny(width=256, height=256, env_pixels=None, with_floor=True):
-    """bunny.obj (4 968 triangles) pre-scaled x10: the quick parity scene."""
+    """bunny.obj (4 968 triangles, about 1.5 units tall): the quick parity scene."""
     sc = Scene()
-    frm, at = (-0.2, 1.2, 3.2), (-0.2, 1.0, 0.0)
+    frm, at = (0.1, 1.1, 3.4), (0.1, 0.7, 0.0)
     focus = float(np.linalg.norm(np.array(at, np.float32) - np.array(frm, np.float32)).astype(np.float32))
     sc.setSimpleCamera(frm, at, (0, 1, 0), 50, width, height, 0.01, focus)
     if env_pixels is not None:
         sc.add_ibl_pixels(env_pixels, also_env=True)
     if with_floor:
         floor = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(0.6, 0.6, 0.6), metalness=0.0, roughness=0.8)
-        t = Transform().scale(5, 5, 1).rotate((-1, 0, 0), 90).translate((0, 0.33, 0))
+        t = Transform().scale(5, 5, 1).rotate((-1, 0, 0), 90).translate((0, -0.0148, 0))
         sc.add_plane(t, floor)
     body = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(0, 1, 0), roughness=0.5, metalness=0.1)
-    sc.addObjectsFromFile(asset("bunny.obj"), body, Transform(), prescale=10.0)
+    sc.addObjectsFromFile(asset("bunny.obj"), body, Transform(), prescale=1.0)
     return sc
 
 
