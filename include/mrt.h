@@ -247,6 +247,37 @@ mrt_status mrt_resolve( mrt_scene* scene,
                         uint32_t placement,
                         void* stream );
 
+/* Diagnostics: evaluates ONE device function of the shading code on `n` rows of host floats
+ * (row strides in floats), so that each function can be compared with a CPU implementation in
+ * isolation.  The reference functions each id corresponds to:
+ *   MATERIAL_EVAL    Material::eval (Material.cpp:983-1013)     in: material, raydir3, normal3, wi3           out: bsdf3, pdf
+ *   MATERIAL_SAMPLE  Material::sample (Material.cpp:1015-1100)  in: material, raydir3, normal3, outside, seq2  out: bsdf3, pdf, wi3
+ *   LIGHT_SAMPLE     Object::sample(inter,u,&pdf) of a ShapeLight's shape (triangle.cpp:86-97, sphere.cpp:191-223)
+ *                                                               in: light, pos3, normal3, outside, u2          out: pos3, normal3, pdf
+ *   LIGHT_PDF        Object::pdf / Sphere::pdf (Object.cpp:13-22, sphere.cpp:225-236)
+ *                                                               in: light, pos3, normal3, wi3                  out: pdf
+ *   IBL              IBL::Le, the texel IBL::sample_Li returns, IBL::pdf_Li (Light.cpp:277-342)
+ *                                                               in: dir3                                       out: Le3, texel3, pdf
+ *   RANDOM_DIR       random_dir (sampling.h:199-211)            in: normal3, seq2                              out: dir3
+ *   SAMPLER          the counter-based sample streams           in: seed, pixel, spp_x, spp_y, sample (uint bit patterns)
+ *                                                               out: camera5, 1D dims 8, 2D dims 16, first 4 engine draws
+ *   CAMERA           SimpleCamera::get_ray (Camera.cpp:37-67)   in: s, t, ulens, vlens                         out: origin3, dir3
+ *   BSDF_TERMS       RDM_Beckmann, RDM_Fresnel, RDM_G1 (bsdf.cpp:43-58,100-118,141-154)
+ *                                                               in: ndoth, alpha, ldoth, ext, int, ddotn       out: D, F, G1
+ * seq2 = the two 32-bit halves of a PCG32 sequence index, passed as float bit patterns. */
+enum {
+    MRT_DBG_MATERIAL_EVAL   = 0,
+    MRT_DBG_MATERIAL_SAMPLE = 1,
+    MRT_DBG_LIGHT_SAMPLE    = 2,
+    MRT_DBG_LIGHT_PDF       = 3,
+    MRT_DBG_IBL             = 4,
+    MRT_DBG_RANDOM_DIR      = 5,
+    MRT_DBG_SAMPLER         = 6,
+    MRT_DBG_CAMERA          = 7,
+    MRT_DBG_BSDF_TERMS      = 8
+};
+mrt_status mrt_debug_eval( mrt_scene* scene, uint32_t fn, uint32_t n, const float* in, uint32_t in_stride, float* out, uint32_t out_stride );
+
 const char* mrt_last_error( void );
 int32_t mrt_version( void );
 

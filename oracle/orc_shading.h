@@ -602,7 +602,13 @@ inline V3 directIllumination( const ShadeScene& sc, const Ray& ray, const Isect&
         }
     }
 
-    V3 bsdf = material_sample( sc, mat, ray, isect, smp, &wi, &scatteringPdf ) * fmax_glm( dot( isect.normal, wi ), 0.f );
+    // integrator.cpp:97-99 multiplies Material::sample(..., &wi, ...) by max(dot(normal, wi), 0) in one
+    // expression.  The two operands of `*` are unsequenced; g++ (the compiler of the reference's
+    // Linux build, and of this container) evaluates the right operand first, so the cosine is taken
+    // with the wi left behind by the LIGHT sample, before Material::sample overwrites it.  Stated
+    // explicitly here so that the result does not depend on the compiler.
+    float cosPrevWi = fmax_glm( dot( isect.normal, wi ), 0.f );
+    V3 bsdf         = material_sample( sc, mat, ray, isect, smp, &wi, &scatteringPdf ) * cosPrevWi;
     if ( !isBlack( bsdf ) && scatteringPdf > 0 ) {
         float weight = 1;
         lightPdf     = light_pdf_Li( sc, li, isect, wi );

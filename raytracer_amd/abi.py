@@ -120,6 +120,8 @@ def hip():
         lib.mrt_render.restype = C.c_int32
         lib.mrt_resolve.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.mrt_resolve.restype = C.c_int32
+        lib.mrt_debug_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32]
+        lib.mrt_debug_eval.restype = C.c_int32
         _hip = lib
     return _hip
 

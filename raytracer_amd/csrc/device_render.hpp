@@ -225,7 +225,11 @@ __global__ void __launch_bounds__( 256 ) shade_kernel( DTrace tr, DShade sh, Pat
                             ps.stmax[id] = s_tmax;
                         }
                     }
-                    V3 bsdf = material_sample( sh, mat, rd, sf, rng, wi, scatteringPdf ) * fmax_glm( dot3( sf.normal, wi ), 0.f );
+                    // integrator.cpp:97-99: `sample(..., &wi, ...) * max(dot(normal, wi), 0)` -- the
+                    // reference as built by g++ evaluates the right operand first, i.e. the cosine
+                    // uses the light-sample direction still in wi; made explicit here.
+                    const float cos_prev_wi = fmax_glm( dot3( sf.normal, wi ), 0.f );
+                    V3 bsdf                 = material_sample( sh, mat, rd, sf, rng, wi, scatteringPdf ) * cos_prev_wi;
                     if ( !is_black( bsdf ) && scatteringPdf > 0 ) {
                         float lp = light.kind == 0 ? light_shape_pdf( tr, light, sf, wi ) : ibl_pdf_Li( sh, wi );
                         if ( lp != 0 ) {

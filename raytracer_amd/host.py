@@ -286,6 +286,16 @@ class DeviceScene:
             raise MrtError("mrt_intersect: %d %s" % (st, lib.mrt_last_error().decode()))
         return (prim, t, u, v, ts) if stats else (prim, t, u, v)
 
+    def debug_eval(self, fn, rows, out_width):
+        """mrt_debug_eval: one device shading function on rows of floats (diagnostics)."""
+        rows = np.ascontiguousarray(rows, np.float32)
+        n, w = rows.shape
+        out = np.zeros((n, out_width), np.float32)
+        st = abi.hip().mrt_debug_eval(self._h, fn, n, rows.ctypes.data_as(abi.f32p), w, out.ctypes.data_as(abi.f32p), out_width)
+        if st != abi.MRT_OK:
+            raise MrtError("mrt_debug_eval: %d %s" % (st, abi.hip().mrt_last_error().decode()))
+        return out
+
     def render(self, params, rgb_sum, stream=None):
         """mrt_render: adds linear radiance sums into rgb_sum ([h,w,3] numpy array or torch CUDA tensor)."""
         lib = abi.hip()
