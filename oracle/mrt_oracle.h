@@ -203,7 +203,8 @@ void orc_render( const mrt_scene_desc* desc,
                  float* rgb_sum,
                  float* per_sample,
                  mrt_render_stats* stats,
-                 mrt_trace_stats* tstats,
+                 mrt_trace_stats* tstats3, /* traversal counters by ray class: continuation, shadow, MIS */
+                 uint64_t* rays3,          /* rays traced per class */
                  int n_threads );
 
 #ifdef __cplusplus

@@ -313,8 +313,8 @@ struct ShadeScene : TraceScene {
 };
 
 struct Counters {
-    mrt_trace_stats t {};
-    uint64_t closest = 0, any = 0;
+    mrt_trace_stats cls[3] {}; // traversal counters by ray class: 0 continuation, 1 shadow, 2 MIS
+    uint64_t rays[3] = { 0, 0, 0 };
 };
 
 // Sampler interface used by the integrator; both samplers provide it.
@@ -533,7 +533,7 @@ inline V3 shapelight_L( V3 color, V3 n, V3 w ) { // Light.cpp:247-249
     return dot( n, w ) > 0.f ? color : v3( 0.f );
 }
 
-bool trace( const ShadeScene& sc, Ray* ray, Isect* isect, Counters& c );
+bool trace( const ShadeScene& sc, Ray* ray, Isect* isect, Counters& c, int cls );
 
 inline V3 light_sample_Li( const ShadeScene& sc, uint32_t li, const Isect& inter, V2 u, SamplerIface& smp, V3* wi, float* pdf, bool* occluded, Counters& c ) {
     const mrt_light& l = sc.d->lights[li];
@@ -545,7 +545,7 @@ inline V3 light_sample_Li( const ShadeScene& sc, uint32_t li, const Isect& inter
         rayS.hasDifferentials = false;
         rayS.shadow           = true;
         Isect temp;
-        *occluded = trace( sc, &rayS, &temp, c );
+        *occluded = trace( sc, &rayS, &temp, c, 1 );
         return shapelight_L( v3( l.color ), pShape.normal, -*wi );
     }
     // IBL::sample_Li (Light.cpp:277-315)
@@ -557,7 +557,7 @@ inline V3 light_sample_Li( const ShadeScene& sc, uint32_t li, const Isect& inter
     rayS.hasDifferentials = false;
     rayS.shadow           = true;
     Isect temp;
-    *occluded = trace( sc, &rayS, &temp, c );
+    *occluded = trace( sc, &rayS, &temp, c, 1 );
 
     V3 dir      = mul( sc.env_inv, rayS.dir );
     float theta = std::acos( dir.y );
@@ -576,10 +576,9 @@ inline V3 light_Le( const ShadeScene& sc, uint32_t li, V3 raydir ) { // Light.h:
     return v3( 0.f );
 }
 
-inline bool trace( const ShadeScene& sc, Ray* ray, Isect* isect, Counters& c ) {
-    if ( ray->shadow ) c.any++;
-    else c.closest++;
-    return intersect_kdtree( sc, ray, isect, &c.t );
+inline bool trace( const ShadeScene& sc, Ray* ray, Isect* isect, Counters& c, int cls ) {
+    c.rays[cls]++;
+    return intersect_kdtree( sc, ray, isect, &c.cls[cls] );
 }
 
 // directIllumination (integrator.cpp:69-120)
@@ -617,7 +616,7 @@ inline V3 directIllumination( const ShadeScene& sc, const Ray& ray, const Isect&
         Ray ray_ref( isect.position + ( wi * acne_eps ), normalize( wi ), 0, 10000 );
         ray_ref.hasDifferentials = false;
         Isect temp;
-        bool found = trace( sc, &ray_ref, &temp, c );
+        bool found = trace( sc, &ray_ref, &temp, c, 2 );
         V3 Li2     = v3( 0.f );
         if ( found ) {
             if ( sc.mat_emissive_sum[temp.materialIndex] ) Li2 = shapelight_L( v3( sc.d->lights[li].color ), temp.normal, -wi );
@@ -635,7 +634,7 @@ inline V3 trace_ray( const ShadeScene& sc, Ray ray, int maxDepth, SamplerIface& 
     V3 throughput = v3( 1.f );
     Isect isect;
     for ( int depth = 0;; depth++ ) {
-        if ( trace( sc, &ray, &isect, c ) ) {
+        if ( trace( sc, &ray, &isect, c, 0 ) ) {
             const mrt_material& mat = sc.d->materials[isect.materialIndex];
             if ( !isBlack( v3( mat.emission ) ) && depth == 0 ) {
                 V3 col0 = sc.d->n_lights > 0 ? v3( sc.d->lights[0].color ) : v3( 0.f );

@@ -57,6 +57,27 @@ def bunny_ibl(width=1920, height=1080, glossy=False, obj="stanford-bunny.obj", p
     return sc
 
 
+def bunny_pair(width=1920, height=1080, env="brown_photostudio_06_1k.hdr", subdivisions=0):
+    """BASELINE config 2: stanford-bunny.obj twice -- one diffuse (scene-20 mat4), one glossy
+    (scene-20 mat5), each placed by its own Transform as the reference places its bunnies
+    (example_scenes.cpp:1439-1457) -- on a Plane floor under the 1k HDR environment."""
+    sc = Scene()
+    frm, at = (0.0, 2.8, 7.5), (0.0, 2.0, 0.0)
+    focus = float(np.linalg.norm(np.array(at, np.float32) - np.array(frm, np.float32)).astype(np.float32))
+    sc.setSimpleCamera(frm, at, (0, 1, 0), 60, width, height, 0.02, focus)
+    if env:
+        sc.add_ibl_file(asset(env), also_env=True)
+    floor = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(0.6, 0.6, 0.6), metalness=0.0, roughness=0.8)
+    sc.add_plane(Transform().scale(10, 10, 1).rotate((-1, 0, 0), 90).translate((0, 0.66, 0)), floor)
+    diffuse = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(0, 1, 0), roughness=0.5, metalness=0.1)
+    glossy = sc.CreateMaterial(abi.MRT_MAT_SPECULAR, albedo=(1, 1, 1), roughness=0.2, metalness=0.9)
+    sc.addObjectsFromFile(asset("stanford-bunny.obj"), diffuse, Transform().translate((-1.5, 0.0, 0)), prescale=20.0,
+                          subdivisions=subdivisions)
+    sc.addObjectsFromFile(asset("stanford-bunny.obj"), glossy, Transform().translate((2.1, 0.0, 0)), prescale=20.0,
+                          subdivisions=subdivisions)
+    return sc
+
+
 def small_bunny(width=256, height=256, env_pixels=None, with_floor=True):
     """bunny.obj (4 968 triangles, about 1.5 units tall): the quick parity scene."""
     sc = Scene()

@@ -61,7 +61,7 @@ def oracle():
         lib.orc_camera_rays.argtypes = [C.POINTER(abi.Camera), C.c_int64] + [vp] * 4
         lib.orc_sample_streams.argtypes = [C.c_uint32] * 5 + [vp] * 3
         lib.orc_render.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RenderParams), C.c_int, vp, vp,
-                                   C.POINTER(abi.RenderStats), C.POINTER(abi.TraceStats), C.c_int]
+                                   C.POINTER(abi.RenderStats), C.POINTER(abi.TraceStats), vp, C.c_int]
         _orc = lib
     return _orc
 
@@ -302,13 +302,15 @@ def oracle_intersect(desc, o, d, tmin, tmax, shadow, stats=False, threads=8):
 def oracle_render(desc, params, sampler_mode=0, threads=8, per_sample=False):
     h, w = params.height, params.width
     img = np.zeros((h, w, 3), np.float32)
-    rs, ts = abi.RenderStats(), abi.TraceStats()
+    rs, ts = abi.RenderStats(), (abi.TraceStats * 3)()
+    rays = np.zeros(3, np.uint64)
     ps = None
     if per_sample:
         rows = (params.row_end or h) - params.row_begin
         ns = (params.sample_end or params.spp_x * params.spp_y) - params.sample_begin
         ps = np.zeros((rows, w, ns, 3), np.float32)
-    oracle().orc_render(desc, C.byref(params), sampler_mode, _p(img), _p(ps), C.byref(rs), C.byref(ts), threads)
+    oracle().orc_render(desc, C.byref(params), sampler_mode, _p(img), _p(ps), C.byref(rs), ts, _p(rays), threads)
+    rs.class_rays = rays
     return img, rs, ts, ps
 
 
