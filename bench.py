@@ -84,18 +84,15 @@ def main():
     dev = DeviceScene(flat, device=local_rank)
     n_nodes, n_refs, depth = tree.counts()
 
+    from raytracer_amd import parallel
+
     spp = SPP_X * SPP_Y
-    params = render_params(WIDTH, HEIGHT, SPP_X, SPP_Y * world, max_depth=MAX_DEPTH, seed=SEED,
-                           sample_begin=rank * spp, sample_end=(rank + 1) * spp)
+    params = parallel.rank_params(WIDTH, HEIGHT, SPP_X, SPP_Y, rank, world, max_depth=MAX_DEPTH, seed=SEED, weak=True)
     img = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        img.zero_()
-        rs = dev.render(params, img, stream=stream)
-        if dist is not None:
-            dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
-        return rs
+        return parallel.render_frame(lambda p, im: dev.render(p, im, stream=stream), params, img, dist)
 
     for _ in range(args.warmup):
         step()

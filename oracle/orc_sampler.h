@@ -118,8 +118,11 @@ struct StratifiedSampler {
     }
     V2 Get2D() { // sampler.cpp:104-109
         if ( cur2D < (int)samples2D.size() ) return samples2D[cur2D++][index];
-        float a = rng.Uniformfloat();
+        // point2( rng.Uniformfloat(), rng.Uniformfloat() ): the two calls are unsequenced; g++
+        // evaluates constructor arguments right to left, so y is drawn first (pinned by the golden
+        // stream recorded from the reference's own sampler.cpp)
         float b = rng.Uniformfloat();
+        float a = rng.Uniformfloat();
         return V2 { a, b };
     }
 };
