@@ -43,14 +43,18 @@ def b_ray(ts, n):
 
 
 def main():
+    global SPP_Y
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel of the CPU sample")
+    ap.add_argument("--cpu-spp", type=int, default=32, help="samples per pixel of the CPU sample")
+    ap.add_argument("--spp-y", type=int, default=16, help="rows of the 16 x N sample grid (profiling runs use fewer)")
+    ap.add_argument("--paths-per-pass", type=int, default=0, help="paths in flight per pass (0 = library default)")
     args = ap.parse_args()
 
+    SPP_Y = args.spp_y
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # started by hand with --gpus N: run the ranks as child processes (never exec after GPU init)
@@ -88,6 +92,7 @@ def main():
 
     spp = SPP_X * SPP_Y
     params = parallel.rank_params(WIDTH, HEIGHT, SPP_X, SPP_Y, rank, world, max_depth=MAX_DEPTH, seed=SEED, weak=True)
+    params.paths_per_pass = args.paths_per_pass
     img = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 

@@ -111,19 +111,31 @@ __global__ void __launch_bounds__( 256 ) generate_kernel( PathState ps, PassInfo
 
 // ------------------------------------------------------------------------------------------------
 // extend: closest hit of the continuation rays.  `queue` == nullptr means the identity queue.
-__global__ void __launch_bounds__( 256 ) extend_kernel( DTrace tr, PathState ps, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_max, float tmax ) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = n_ptr ? *n_ptr : n_max;
-    if ( i >= n ) return;
-    const uint32_t id = queue ? queue[i] : i;
-    DHit h;
+struct ExtendIO {
+    PathState ps;
+    const uint32_t* queue;
+    float tmax;
+    MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
+        id = queue ? queue[i] : i;
+        o  = mk3( ps.ox[id], ps.oy[id], ps.oz[id] );
+        d  = mk3( ps.dx[id], ps.dy[id], ps.dz[id] );
+        t0 = 0.f;
+        t1 = tmax;
+    }
+    MRT_DEV void store( uint32_t id, bool, const DHit& h ) const {
+        ps.h_prim[id]    = h.prim;
+        ps.h_t[id]       = h.t;
+        ps.h_u[id]       = h.u;
+        ps.h_v[id]       = h.v;
+        ps.h_outside[id] = h.outside;
+    }
+};
+
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max ) {
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    lds_u32* lp = (lds_u32*)lds;
     DStats st;
-    trace_ray<false, false>( tr, mk3( ps.ox[id], ps.oy[id], ps.oz[id] ), mk3( ps.dx[id], ps.dy[id], ps.dz[id] ), 0.f, tmax, h, st );
-    ps.h_prim[id]    = h.prim;
-    ps.h_t[id]       = h.t;
-    ps.h_u[id]       = h.u;
-    ps.h_v[id]       = h.v;
-    ps.h_outside[id] = h.outside;
+    trace_stream<false, false, false>( tr, lp, io, n_ptr ? *n_ptr : n_max, st );
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,43 +286,89 @@ __global__ void __launch_bounds__( 256 ) shade_kernel( DTrace tr, DShade sh, Pat
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__( 256 ) connect_shadow_kernel( DTrace tr, PathState ps, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count ) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if ( i >= *count ) return;
-    const uint32_t id = queue[i];
-    DHit h;
-    DStats st;
-    bool occluded = trace_ray<true, false>( tr, mk3( ps.sox[id], ps.soy[id], ps.soz[id] ), mk3( ps.sdx[id], ps.sdy[id], ps.sdz[id] ), 0.f, ps.stmax[id], h, st );
+// connect_shadow: any-hit traversal of the shadow rays.
+struct ShadowIO {
+    PathState ps;
+    const uint32_t* queue;
+    MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
+        id = queue[i];
+        o  = mk3( ps.sox[id], ps.soy[id], ps.soz[id] );
+        d  = mk3( ps.sdx[id], ps.sdy[id], ps.sdz[id] );
+        t0 = 0.f;
+        t1 = ps.stmax[id];
+    }
     // integrator.cpp:88: `if (vis) Li = 0` -- the light term was the only term in DI so far
-    if ( occluded ) ps.dix[id] = ps.diy[id] = ps.diz[id] = 0.f;
+    MRT_DEV void store( uint32_t id, bool occluded, const DHit& ) const {
+        if ( occluded ) ps.dix[id] = ps.diy[id] = ps.diz[id] = 0.f;
+    }
+};
+
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count ) {
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    lds_u32* lp = (lds_u32*)lds;
+    DStats st;
+    trace_stream<true, true, false>( tr, lp, io, *count, st );
 }
 
-__global__ void __launch_bounds__( 256 ) connect_mis_kernel( DTrace tr, DShade sh, PathState ps, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count ) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if ( i >= *count ) return;
-    const uint32_t id = queue[i];
-    DHit h;
-    DStats st;
-    V3 o = mk3( ps.mox[id], ps.moy[id], ps.moz[id] ), d = mk3( ps.mdx[id], ps.mdy[id], ps.mdz[id] );
-    bool found = trace_ray<false, false>( tr, o, d, 0.f, 10000.f, h, st );
-    const uint32_t li = ps.mlight[id];
-    V3 Li             = mk3( 0.f );
-    if ( found ) { // integrator.cpp:108-113
-        const uint32_t flags = __float_as_uint( tr.prims[3 * (size_t)h.prim].w );
-        if ( flags & MRT_PRIM_EMISSIVE_SUM ) {
-            Surf sf = surface_from_hit( tr, sh, o, d, h );
-            // `wi` of the reference is the un-normalised sample direction; the ray direction is
-            // normalize(wi) and wi is already unit length up to rounding, the sign test is the same
-            Li = dot3( sf.normal, -d ) > 0.f ? ld3( sh.lights[li].color ) : mk3( 0.f );
-        }
+// connect_mis: closest-hit traversal of the MIS rays.  The hit goes to the h_* arrays of the path
+// (shade has consumed the continuation hit by now and the next extend has not run yet);
+// mis_resolve_kernel turns it into the bsdf-sampling term.
+struct MisIO {
+    PathState ps;
+    const uint32_t* queue;
+    MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
+        id = queue[i];
+        o  = mk3( ps.mox[id], ps.moy[id], ps.moz[id] );
+        d  = mk3( ps.mdx[id], ps.mdy[id], ps.mdz[id] );
+        t0 = 0.f;
+        t1 = 10000.f;
     }
-    else if ( sh.lights[li].kind == 1 ) { Li = ibl_Le( sh, d ); } // Light::Le is black for shape lights
-    if ( !is_black( Li ) ) {
-        V3 bsdf = mk3( ps.mbx[id], ps.mby[id], ps.mbz[id] );
-        V3 c    = bsdf * Li * ps.mw[id] / ps.mpdf[id];
-        ps.dix[id] += c.x;
-        ps.diy[id] += c.y;
-        ps.diz[id] += c.z;
+    MRT_DEV void store( uint32_t id, bool, const DHit& h ) const {
+        ps.h_prim[id]    = h.prim;
+        ps.h_t[id]       = h.t;
+        ps.h_u[id]       = h.u;
+        ps.h_v[id]       = h.v;
+        ps.h_outside[id] = h.outside;
+    }
+};
+
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count ) {
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    lds_u32* lp = (lds_u32*)lds;
+    DStats st;
+    trace_stream<false, false, false>( tr, lp, io, *count, st );
+}
+
+__global__ void __launch_bounds__( 256 ) mis_resolve_kernel( DTrace tr, DShade sh, PathState ps, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count ) {
+    const uint32_t n = *count;
+    for ( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x ) {
+        const uint32_t id = queue[i];
+        DHit h;
+        h.prim    = ps.h_prim[id];
+        h.t       = ps.h_t[id];
+        h.u       = ps.h_u[id];
+        h.v       = ps.h_v[id];
+        h.outside = ps.h_outside[id];
+        const V3 o = mk3( ps.mox[id], ps.moy[id], ps.moz[id] ), d = mk3( ps.mdx[id], ps.mdy[id], ps.mdz[id] );
+        const uint32_t li = ps.mlight[id];
+        V3 Li             = mk3( 0.f );
+        if ( h.prim >= 0 ) { // integrator.cpp:108-113
+            const uint32_t flags = __float_as_uint( tr.prims[3 * (size_t)h.prim].w );
+            if ( flags & MRT_PRIM_EMISSIVE_SUM ) {
+                Surf sf = surface_from_hit( tr, sh, o, d, h );
+                // `wi` of the reference is the un-normalised sample direction; the ray direction is
+                // normalize(wi) and wi is already unit length up to rounding, the sign test is the same
+                Li = dot3( sf.normal, -d ) > 0.f ? ld3( sh.lights[li].color ) : mk3( 0.f );
+            }
+        }
+        else if ( sh.lights[li].kind == 1 ) { Li = ibl_Le( sh, d ); } // Light::Le is black for shape lights
+        if ( !is_black( Li ) ) {
+            V3 bsdf = mk3( ps.mbx[id], ps.mby[id], ps.mbz[id] );
+            V3 c    = bsdf * Li * ps.mw[id] / ps.mpdf[id];
+            ps.dix[id] += c.x;
+            ps.diy[id] += c.y;
+            ps.diz[id] += c.z;
+        }
     }
 }
 

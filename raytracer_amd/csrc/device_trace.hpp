@@ -1,9 +1,9 @@
 // kd-tree traversal and ray/primitive intersection for the gfx950 kernels.
 //
-// One ray per lane.  The algorithm, its comparisons and its arithmetic are those of the
-// reference's intersectKdTree (kdtree.cpp:162-180, 467-613; shapes/triangle.cpp:4-40,
-// shapes/sphere.cpp:52-133, shapes/plane.cpp:6-30), so the primitive id, t and barycentrics of
-// every hit are bit-identical to the CPU path:
+// The algorithm, its comparisons and its arithmetic are those of the reference's intersectKdTree
+// (kdtree.cpp:162-180, 467-613; shapes/triangle.cpp:4-40, shapes/sphere.cpp:52-133,
+// shapes/plane.cpp:6-30), so the primitive id, t and barycentrics of every hit are bit-identical
+// to the CPU path:
 //   - the root box (already padded by the builder) clips [tmin, tmax] with the multiply-by-invdir
 //     slab test; inner nodes use a true division t = (split - o[axis]) / d[axis];
 //   - near = left iff (split - o[axis]) > 0; (t > b || t < 0) -> near only; t < a -> far only;
@@ -14,8 +14,19 @@
 //     strictly nearer, and the search ends at the first leaf that produced a hit;
 //   - shadow (any-hit) rays stop at the first hit on a non-emissive primitive; hits on emissive
 //     primitives are ignored but still shrink tmax for the rest of that leaf;
-//   - planes live outside the tree and are tested afterwards against the ORIGINAL interval
-//     (upper end replaced by the tree hit distance if there was one), as a closest-hit ray.
+//   - planes live outside the tree.  The reference tests them after the tree, as a closest-hit ray
+//     over the ORIGINAL interval whose upper end is the tree hit distance if there was one; a plane
+//     replaces a tree hit only if strictly nearer.  That outcome does not depend on the order, so
+//     here the planes are tested when a ray is fetched (nearest plane, first one on ties; for
+//     any-hit rays the first accepted plane) and merged with the tree result when the ray retires.
+//
+// Execution model: streaming traversal.  A wave owns an interleaved share of the ray list and every
+// lane is a small state machine (idle / inner / leaf references / primitive test).  One trip of
+// the wave's loop performs, for every lane, the work that depends on the loads issued in the trip
+// before and issues the next loads, so a trip costs one memory round trip however the lanes'
+// states are mixed; lanes whose ray retired are refilled from the wave's share once enough of
+// them are idle.  Rays differ in length by orders of magnitude, so without the refill a wave runs
+// at the pace of its longest ray with most lanes idle.
 //
 // The deferred-node stack stores (node, tmax) only: the entry interval of a popped node is always
 // the exit value b of the leaf visited just before it (the same float, carried by assignment),
@@ -25,6 +36,13 @@
 
 #define MRT_STACK_MAX 64
 #define MRT_ACNE_EPS 1e-4f
+#define MRT_XF_LDS 64          // transforms kept in LDS (12 floats each); the rest are read from HBM
+#ifndef MRT_REFILL_MIN
+#define MRT_REFILL_MIN 8 // idle lanes that trigger a refill of the wave
+#endif
+#ifndef MRT_VOTE
+#define MRT_VOTE 0
+#endif
 
 // prim record: 3 x float4
 //   q0 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane),
@@ -47,6 +65,7 @@ struct DTrace {
     const uint32_t* out_of_tree;
     uint32_t n_nodes;
     uint32_t n_out;
+    uint32_t n_xforms;
     float root_min[3];
     float root_max[3];
 };
@@ -61,248 +80,473 @@ struct DStats {
     uint32_t inner, leaves, refs, tests;
 };
 
-// Per-lane cache of the ray in the object space of the most recently used transform.
-struct XfRay {
-    uint32_t id;
-    V3 o, d;
-};
+// LDS of a traversal block (MRT_TRACE_BLOCK lanes).  Everything a lane touches rarely lives here
+// instead of in registers, slot-major so that the lanes of a wave fall on distinct banks:
+//   transform table   inv (9) + translation (3) of the first MRT_XF_LDS transforms
+//   stack             the first MRT_STACK_LDS deferred nodes of every lane (deeper ones in scratch)
+//   object-space ray  origin and direction under the lane's current transform
+//   hit record        the accepted hit of the current leaf (prim, u, v, outside); until there is
+//                     one, (-1, 0, 0, tmax the ray came with), which is what a miss reports
+//   plane record      the plane hit found when the ray was fetched (prim, t, u, v)
+#ifndef MRT_STACK_LDS
+#define MRT_STACK_LDS 6
+#endif
+#define MRT_TRACE_BLOCK 256
+#define MRT_LDS_XF 0
+#define MRT_LDS_STACK ( MRT_LDS_XF + MRT_XF_LDS * 12 )
+#define MRT_LDS_XRO ( MRT_LDS_STACK + MRT_STACK_LDS * MRT_TRACE_BLOCK * 2 )
+#define MRT_LDS_XRD ( MRT_LDS_XRO + MRT_TRACE_BLOCK * 4 )
+#define MRT_LDS_OUT ( MRT_LDS_XRD + MRT_TRACE_BLOCK * 4 )
+#define MRT_LDS_PL ( MRT_LDS_OUT + MRT_TRACE_BLOCK * 4 )
+#define MRT_TRACE_LDS_WORDS ( MRT_LDS_PL + MRT_TRACE_BLOCK * 4 )
 
-MRT_DEV void to_object( const DTrace& s, uint32_t xf, V3 wo, V3 wd, XfRay& c ) {
-    if ( xf == c.id ) return;
-    c.id = xf;
-    if ( xf == 0 ) { // identity: 1*x + 0*y + 0*z leaves every finite component unchanged
-        c.o = wo;
-        c.d = wd;
-        return;
-    }
-    const DXf& t = s.xforms[xf];
-    // Object::transformRay (Object.cpp:8-11): o' = inv * (o - T), d' = inv * d
-    c.o = mat_mul( t.inv, wo - mk3( t.t[0], t.t[1], t.t[2] ) );
-    c.d = mat_mul( t.inv, wd );
+typedef __attribute__( ( address_space( 3 ) ) ) uint32_t lds_u32;
+typedef __attribute__( ( address_space( 3 ) ) ) float lds_f32;
+typedef float v4f __attribute__( ( ext_vector_type( 4 ) ) );
+typedef uint32_t v2u __attribute__( ( ext_vector_type( 2 ) ) );
+typedef __attribute__( ( address_space( 3 ) ) ) v4f lds_f4;
+typedef __attribute__( ( address_space( 3 ) ) ) v2u lds_u2;
+MRT_DEV v4f mk4( float x, float y, float z, float w ) {
+    v4f r;
+    r.x = x, r.y = y, r.z = z, r.w = w;
+    return r;
 }
 
-// Object::intersect for one primitive against the ray interval [tmin, tmax]; on acceptance tmax
-// becomes the hit distance.
-MRT_DEV bool prim_intersect( const DTrace& s, uint32_t obj, V3 wo, V3 wd, float tmin, float& tmax, XfRay& xr, DHit& h ) {
-    const float4 q0      = s.prims[3 * (size_t)obj];
-    const uint32_t flags = __float_as_uint( q0.w );
-    const uint32_t kind  = flags & 3u;
-    to_object( s, flags >> MRT_PRIM_XF_SHIFT, wo, wd, xr );
-    const V3 origin = xr.o, dir = xr.d;
-    if ( kind == MRT_PRIM_TRI ) {
-        const float4 q1 = s.prims[3 * (size_t)obj + 1];
-        const float4 q2 = s.prims[3 * (size_t)obj + 2];
-        const V3 p1 = mk3( q0.x, q0.y, q0.z ), v1v2 = mk3( q1.x, q1.y, q1.z ), v1v3 = mk3( q1.w, q2.x, q2.y );
-        V3 c      = cross3( dir, v1v3 );
-        float det = dot3( v1v2, c );
-        if ( det > -MRT_ACNE_EPS && det < MRT_ACNE_EPS ) return false;
-        float inv_det = 1.f / det;
-        V3 sv         = origin - p1;
-        float u       = dot3( sv, c ) * inv_det;
-        if ( u < 0.f || u > 1.f ) return false;
-        V3 q    = cross3( sv, v1v2 );
-        float v = dot3( dir, q ) * inv_det;
-        if ( v < 0.f || u + v > 1.f ) return false;
-        float t = dot3( v1v3, q ) * inv_det;
-        if ( t >= tmin && t <= tmax ) {
-            tmax      = t;
-            h.prim    = (int32_t)obj;
-            h.t       = t;
-            h.u       = u;
-            h.v       = v;
-            h.outside = !( det < 0.f );
-            return true;
-        }
-        return false;
+// Copies inv (9 floats) and translation (3 floats) of the first MRT_XF_LDS transforms into LDS.
+// Every thread of the block must call it; it ends with a barrier.
+MRT_DEV void stage_transforms( const DTrace& s, lds_f32* xf_lds ) {
+    const uint32_t n = ( s.n_xforms < MRT_XF_LDS ? s.n_xforms : MRT_XF_LDS ) * 12u;
+    for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) {
+        const uint32_t x = i / 12u, k = i - x * 12u;
+        xf_lds[i]        = k < 9u ? s.xforms[x].inv[k] : s.xforms[x].t[k - 9u];
     }
-    if ( kind == MRT_PRIM_SPHERE ) { // unit sphere in object space
-        V3 oc       = origin;
-        float a     = dot3( dir, dir );
-        float b     = 2.f * dot3( dir, oc );
-        float c     = dot3( oc, oc ) - 1.f;
-        float delta = b * b - 4.f * a * c;
-        float t;
-        if ( delta == 0 ) {
-            t = -b / ( 2.f * a );
-            if ( !( t >= tmin && t <= tmax ) ) return false;
-            // the one-root branch takes its normal from the world hit point mapped back
-            V3 pos         = wo + ( t * wd );
-            const DXf& xf  = s.xforms[flags >> MRT_PRIM_XF_SHIFT];
-            V3 objectPoint = ( flags >> MRT_PRIM_XF_SHIFT ) == 0 ? pos : mat_mul( xf.inv, pos - mk3( xf.t[0], xf.t[1], xf.t[2] ) );
-            h.outside      = dot3( dir, objectPoint ) < 0;
+    __syncthreads();
+}
+
+// Object::transformRay (Object.cpp:8-11): o' = inv * (o - T), d' = inv * d
+MRT_DEV void transform_ray( const DTrace& s, const lds_f32* xf_lds, uint32_t xf, V3 wo, V3 wd, V3& oo, V3& od ) {
+    float inv[9], t[3];
+    if ( xf < MRT_XF_LDS ) {
+        const lds_f32* p = xf_lds + xf * 12u;
+        for ( int k = 0; k < 9; k++ )
+            inv[k] = p[k];
+        t[0] = p[9], t[1] = p[10], t[2] = p[11];
+    }
+    else { // beyond the staged table: straight from HBM (four 16-byte loads, unlike the LDS path)
+        const float4* g = (const float4*)&s.xforms[xf];
+        const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+        inv[0] = g0.x, inv[1] = g0.y, inv[2] = g0.z, inv[3] = g0.w;
+        inv[4] = g1.x, inv[5] = g1.y, inv[6] = g1.z, inv[7] = g1.w;
+        inv[8] = g2.x, t[0] = g2.y, t[1] = g2.z, t[2] = g2.w;
+    }
+    oo = mat_mul( inv, wo - mk3( t[0], t[1], t[2] ) );
+    od = mat_mul( inv, wd );
+}
+
+// Möller-Trumbore as shapes/triangle.cpp:4-40 evaluates it.  Returns true when the hit is accepted
+// into [tmin, tmax]; det is returned for the sidedness.
+MRT_DEV bool tri_test( V3 origin, V3 dir, float4 q0, float4 q1, float2 q2, float tmin, float tmax, float& t, float& u, float& v, float& det ) {
+    const V3 p1 = mk3( q0.x, q0.y, q0.z ), v1v2 = mk3( q1.x, q1.y, q1.z ), v1v3 = mk3( q1.w, q2.x, q2.y );
+    V3 c = cross3( dir, v1v3 );
+    det  = dot3( v1v2, c );
+    if ( det > -MRT_ACNE_EPS && det < MRT_ACNE_EPS ) return false;
+    float inv_det = 1.f / det;
+    V3 sv         = origin - p1;
+    u             = dot3( sv, c ) * inv_det;
+    if ( u < 0.f || u > 1.f ) return false;
+    V3 q = cross3( sv, v1v2 );
+    v    = dot3( dir, q ) * inv_det;
+    if ( v < 0.f || u + v > 1.f ) return false;
+    t = dot3( v1v3, q ) * inv_det;
+    return t >= tmin && t <= tmax;
+}
+
+// Unit sphere in object space (shapes/sphere.cpp:52-133).  `wo`, `wd`: world ray (the one-root
+// branch maps the world hit point back through the inverse transform).
+MRT_DEV bool sphere_test( const DTrace& s, const lds_f32* xf_lds, uint32_t xf, V3 origin, V3 dir, V3 wo, V3 wd, float tmin, float tmax, float& t, bool& outside ) {
+    V3 oc       = origin;
+    float a     = dot3( dir, dir );
+    float b     = 2.f * dot3( dir, oc );
+    float c     = dot3( oc, oc ) - 1.f;
+    float delta = b * b - 4.f * a * c;
+    if ( delta == 0 ) {
+        t = -b / ( 2.f * a );
+        if ( !( t >= tmin && t <= tmax ) ) return false;
+        V3 pos         = wo + ( t * wd );
+        V3 objectPoint = pos;
+        if ( xf != 0 ) {
+            V3 unused;
+            transform_ray( s, xf_lds, xf, pos, mk3( 0.f ), objectPoint, unused );
         }
-        else if ( delta > 0 ) {
-            float sq = sqrtf( delta );
-            float t1 = ( -b + sq ) / ( 2.f * a );
-            float t2 = ( -b - sq ) / ( 2.f * a );
-            bool in1 = t1 >= tmin && t1 < tmax, in2 = t2 >= tmin && t2 < tmax;
-            if ( in1 && in2 ) t = ( t2 < t1 ) ? t2 : t1;
-            else if ( in1 ) t = t1;
-            else if ( in2 ) t = t2;
-            else return false;
-            V3 objectNormal = normalize3( origin + ( t * dir ) );
-            h.outside       = dot3( dir, objectNormal ) < 0;
-        }
-        else { return false; }
-        tmax   = t;
-        h.prim = (int32_t)obj;
-        h.t    = t;
-        h.u = h.v = 0.f;
+        outside = dot3( dir, objectPoint ) < 0;
         return true;
     }
-    // plane: unit square z = 0, |x|,|y| <= 1 in object space; ignores tmin (plane.cpp:20)
-    float t = -origin.z / dir.z;
+    if ( delta > 0 ) {
+        float sq = sqrtf( delta );
+        float t1 = ( -b + sq ) / ( 2.f * a );
+        float t2 = ( -b - sq ) / ( 2.f * a );
+        bool in1 = t1 >= tmin && t1 < tmax, in2 = t2 >= tmin && t2 < tmax;
+        if ( in1 && in2 ) t = ( t2 < t1 ) ? t2 : t1;
+        else if ( in1 ) t = t1;
+        else if ( in2 ) t = t2;
+        else return false;
+        V3 objectNormal = normalize3( origin + ( t * dir ) );
+        outside         = dot3( dir, objectNormal ) < 0;
+        return true;
+    }
+    return false;
+}
+
+// Unit square z = 0, |x|,|y| <= 1 in object space; ignores tmin (shapes/plane.cpp:6-30).
+MRT_DEV bool plane_test( V3 origin, V3 dir, float tmax, float& t, float& u, float& v ) {
+    t = -origin.z / dir.z;
     if ( t < 0 || t > tmax ) return false;
     V3 x = origin + t * dir;
     if ( x.x < -1 || x.x > 1 || x.y < -1 || x.y > 1 ) return false;
-    tmax      = t;
-    h.prim    = (int32_t)obj;
-    h.t       = t;
-    h.u       = ( 1.f + x.x ) * .5f; // Intersection::u, v of a plane hit
-    h.v       = ( 1.f + x.y ) * .5f;
-    h.outside = 1;
+    u = ( 1.f + x.x ) * .5f; // Intersection::u, v of a plane hit
+    v = ( 1.f + x.y ) * .5f;
     return true;
 }
 
-template <bool ANY, bool STATS>
-MRT_DEV bool trace_ray( const DTrace& s, V3 o, V3 d, float ray_tmin, float ray_tmax, DHit& out, DStats& st ) {
-    bool found = false;
-    XfRay xr;
-    xr.id = 0xffffffffu;
-    xr.o = xr.d = mk3( 0.f );
-    const float orig_tmin = ray_tmin, orig_tmax = ray_tmax;
-    out.prim = -1;
-    out.t    = ray_tmax;
-    out.u = out.v = 0.f;
-    out.outside   = 0;
+// intersectAabb on the root box (kdtree.cpp:162-180): clips [ray_tmin, ray_tmax], false on a miss.
+MRT_DEV bool clip_root( const DTrace& s, V3 o, V3 d, float& ray_tmin, float& ray_tmax ) {
+    if ( s.n_nodes == 0 ) return false;
+    const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
+    const bool sx = !( d.x >= 0 ), sy = !( d.y >= 0 ), sz = !( d.z >= 0 );
+    float tmin  = ( ( sx ? s.root_max[0] : s.root_min[0] ) - o.x ) * ix;
+    float tmax  = ( ( sx ? s.root_min[0] : s.root_max[0] ) - o.x ) * ix;
+    float tymin = ( ( sy ? s.root_max[1] : s.root_min[1] ) - o.y ) * iy;
+    float tymax = ( ( sy ? s.root_min[1] : s.root_max[1] ) - o.y ) * iy;
+    if ( ( tmin > tymax ) || ( tymin > tmax ) ) return false;
+    if ( tymin > tmin ) tmin = tymin;
+    if ( tymax < tmax ) tmax = tymax;
+    float tzmin = ( ( sz ? s.root_max[2] : s.root_min[2] ) - o.z ) * iz;
+    float tzmax = ( ( sz ? s.root_min[2] : s.root_max[2] ) - o.z ) * iz;
+    if ( ( tmin > tzmax ) || ( tzmin > tmax ) ) return false;
+    if ( tzmin > tmin ) tmin = tzmin;
+    if ( tzmax < tmax ) tmax = tzmax;
+    if ( tmin > ray_tmin ) ray_tmin = tmin;
+    if ( tmax < ray_tmax ) ray_tmax = tmax;
+    return true;
+}
 
-    // ---- intersectAabb on the root box (kdtree.cpp:162-180)
-    bool in_box = false;
-    if ( s.n_nodes > 0 ) {
-        const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
-        const bool sx = !( d.x >= 0 ), sy = !( d.y >= 0 ), sz = !( d.z >= 0 );
-        float tmin  = ( ( sx ? s.root_max[0] : s.root_min[0] ) - o.x ) * ix;
-        float tmax  = ( ( sx ? s.root_min[0] : s.root_max[0] ) - o.x ) * ix;
-        float tymin = ( ( sy ? s.root_max[1] : s.root_min[1] ) - o.y ) * iy;
-        float tymax = ( ( sy ? s.root_min[1] : s.root_max[1] ) - o.y ) * iy;
-        in_box      = !( ( tmin > tymax ) || ( tymin > tmax ) );
-        if ( in_box ) {
-            if ( tymin > tmin ) tmin = tymin;
-            if ( tymax < tmax ) tmax = tymax;
-            float tzmin = ( ( sz ? s.root_max[2] : s.root_min[2] ) - o.z ) * iz;
-            float tzmax = ( ( sz ? s.root_min[2] : s.root_max[2] ) - o.z ) * iz;
-            in_box      = !( ( tmin > tzmax ) || ( tzmin > tmax ) );
-            if ( in_box ) {
-                if ( tzmin > tmin ) tmin = tzmin;
-                if ( tzmax < tmax ) tmax = tzmax;
-                if ( tmin > ray_tmin ) ray_tmin = tmin;
-                if ( tmax < ray_tmax ) ray_tmax = tmax;
+// Lane states of the streaming traversal.
+#define MRT_ST_IDLE 0u  // no ray
+#define MRT_ST_INNER 1u // node record in flight
+#define MRT_ST_REFS 2u  // first two leaf references in flight
+#define MRT_ST_TEST 3u  // record of the current primitive in flight
+#define MRT_ST_FRESH 4u // fetched in this trip: the root node goes in flight at its end
+
+// Byte-offset loads: tables are addressed as base + 32-bit byte offset (checked at scene creation),
+// which the hardware forms from a scalar base and one vector register.
+MRT_DEV uint2 ld_node( const DTrace& s, uint32_t node ) {
+    return *(const uint2*)( (const char*)s.nodes + ( node << 3 ) );
+}
+MRT_DEV uint32_t ld_ref( const DTrace& s, uint32_t i ) {
+    return *(const uint32_t*)( (const char*)s.refs + ( i << 2 ) );
+}
+MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
+    return *(const float4*)( (const char*)s.prims + ( obj * 48u + k * 16u ) );
+}
+
+// Traces rays 0..n-1 of `io` with the whole grid.
+//   io.load(i, tag, o, d, tmin, tmax)  fetches ray i; `tag` is handed back to store
+//   io.store(tag, found, hit)          consumes the result (hit.prim = -1 when nothing was hit)
+// ANY: shadow-ray semantics.  BOOL_ONLY (with ANY): only `found` is meaningful, so a ray that hits
+// a plane retires without entering the tree.  Every thread of the grid must call this (it uses
+// wave-wide votes and a block barrier); blockDim.x must be MRT_TRACE_BLOCK; `lds` must hold
+// MRT_TRACE_LDS_WORDS 32-bit words.
+template <bool ANY, bool BOOL_ONLY, bool STATS, class IO>
+MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t n, DStats& st ) {
+    const lds_f32* xf_lds = (const lds_f32*)( lds + MRT_LDS_XF );
+    stage_transforms( s, (lds_f32*)( lds + MRT_LDS_XF ) );
+    lds_u2* stack_lds = (lds_u2*)( lds + MRT_LDS_STACK ) + threadIdx.x;
+    lds_f4* xro_lds   = (lds_f4*)( lds + MRT_LDS_XRO ) + threadIdx.x;
+    lds_f4* xrd_lds   = (lds_f4*)( lds + MRT_LDS_XRD ) + threadIdx.x;
+    lds_f4* out_lds   = (lds_f4*)( lds + MRT_LDS_OUT ) + threadIdx.x;
+    lds_f4* pl_lds    = (lds_f4*)( lds + MRT_LDS_PL ) + threadIdx.x;
+
+    // Ray list shares: 64-ray chunks dealt round-robin to the waves of the grid; `taken` counts
+    // the rays this wave has fetched from its share.
+    const uint32_t n_chunks = ( n + 63u ) >> 6;
+    const uint32_t wave     = ( blockIdx.x * blockDim.x + threadIdx.x ) >> 6;
+    const uint32_t n_waves  = ( gridDim.x * blockDim.x ) >> 6;
+    uint32_t taken = 0;
+
+    uint32_t state = MRT_ST_IDLE;
+    uint32_t tag   = 0;
+    V3 o = mk3( 0.f ), d = mk3( 0.f );
+    float a = 0.f, b = 0.f, tmax = 0.f;
+    // Load registers: (L0.x, L0.y) is the node record in state INNER; L0, L1, L2 the primitive
+    // record in state TEST.
+    float4 L0 = make_float4( 0.f, 0.f, 0.f, 0.f ), L1 = L0;
+    float2 L2 = make_float2( 0.f, 0.f );
+    uint32_t ptr = 0, end = 0, obj = 0, next = 0, next2 = 0;
+    uint32_t xr_id = 0;    // transform of the object-space ray in LDS
+    bool has       = false; // the current leaf has produced a hit (record in LDS, distance = tmax)
+    bool has_pl    = false; // a plane was hit at fetch time (record in LDS)
+    uint32_t pl_tests = 0;  // planes the reference would have tested for this ray (counters only)
+    v2u stack_deep[MRT_STACK_MAX - MRT_STACK_LDS];
+    int sp = 0;
+
+    for ( ;; ) {
+        // ---------------------------------------------------------------- refill
+        const unsigned long long idle = __ballot( state == MRT_ST_IDLE );
+        const uint32_t n_idle         = (uint32_t)__popcll( idle );
+        const bool more               = ( taken >> 6 ) * n_waves + wave < n_chunks;
+        if ( !more && n_idle == 64u ) break;
+        if ( more && n_idle >= MRT_REFILL_MIN ) {
+            if ( state == MRT_ST_IDLE ) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( idle >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)idle, 0u ) );
+                const uint32_t j    = taken + rank;
+                const uint32_t idx  = ( ( j >> 6 ) * n_waves + wave ) * 64u + ( j & 63u );
+                if ( idx < n ) {
+                    float ray_tmin, ray_tmax;
+                    io.load( idx, tag, o, d, ray_tmin, ray_tmax );
+                    xr_id    = 0;
+                    *out_lds = mk4( __uint_as_float( 0xffffffffu ), 0.f, 0.f, ray_tmax );
+                    *xro_lds = mk4( o.x, o.y, o.z, 0.f );
+                    *xrd_lds = mk4( d.x, d.y, d.z, 0.f );
+                    // planes (kdtree.cpp:563-611), over the original interval: nearest one, the
+                    // first on ties; an any-hit ray stops at the first accepted plane
+                    has_pl      = false;
+                    float btmax = ray_tmax;
+                    if ( STATS ) pl_tests = s.n_out;
+                    for ( uint32_t k = 0; k < s.n_out; k++ ) {
+                        const uint32_t po = s.out_of_tree[k];
+                        const uint32_t xf = __float_as_uint( ld_prim( s, po, 0 ).w ) >> MRT_PRIM_XF_SHIFT;
+                        V3 oo = o, od = d;
+                        if ( xf != 0 ) transform_ray( s, xf_lds, xf, o, d, oo, od );
+                        float t, u, v;
+                        if ( plane_test( oo, od, btmax, t, u, v ) ) {
+                            btmax = t; // accepted: later planes must be at least as near,
+                            // and replace this one only if strictly nearer
+                            bool better = true;
+                            if ( has_pl ) {
+                                const v4f cur = *pl_lds;
+                                better           = t < cur.y;
+                            }
+                            if ( better ) *pl_lds = mk4( __uint_as_float( po ), t, u, v );
+                            has_pl = true;
+                            if ( ANY ) {
+                                if ( STATS ) pl_tests = k + 1;
+                                break;
+                            }
+                        }
+                    }
+                    if ( ANY && BOOL_ONLY && has_pl ) {
+                        DHit h;
+                        h.prim = 0, h.t = 0.f, h.u = h.v = 0.f, h.outside = 1;
+                        io.store( tag, true, h );
+                    }
+                    else if ( clip_root( s, o, d, ray_tmin, ray_tmax ) ) {
+                        a     = ray_tmin;
+                        b     = ray_tmax;
+                        sp    = 0;
+                        has   = false;
+                        state = MRT_ST_FRESH;
+                    }
+                    else {
+                        if ( STATS ) st.tests += pl_tests;
+                        DHit h;
+                        h.prim = -1, h.t = ray_tmax, h.u = h.v = 0.f, h.outside = 0;
+                        if ( has_pl ) {
+                            const v4f r = *pl_lds;
+                            h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
+                        }
+                        io.store( tag, has_pl, h );
+                    }
+                }
             }
+            taken += n_idle;
         }
-    }
 
-    // ---- traverse (kdtree.cpp:467-553)
-    if ( in_box ) {
-        uint2 stack[MRT_STACK_MAX];
-        int sp        = 0;
-        float a       = ray_tmin, b = ray_tmax;
+        // ---------------------------------------------------------------- one step per lane
+        // Compute first (this consumes the loads of the trip before), issue the next loads last.
+        // Only one kind of step runs per trip, the one more lanes are waiting for (a wave-uniform
+        // choice): every trip then costs the instructions of one branch instead of all of them,
+        // and the lanes of the other kind keep their loaded operands until their turn.
+        bool pop = false, retire = false, advance = false, want_refs = false, want_node = false;
         uint32_t node = 0;
-        while ( true ) {
-            uint2 nd = s.nodes[node];
-            while ( ( nd.y & 3u ) != 3u ) {
+        const uint32_t n_inner = (uint32_t)__popcll( __ballot( state == MRT_ST_INNER ) );
+        const uint32_t n_leaf  = (uint32_t)__popcll( __ballot( state == MRT_ST_REFS || state == MRT_ST_TEST ) );
+        const bool inner_trip  = MRT_VOTE ? n_inner >= n_leaf : true;
+        const bool leaf_trip   = MRT_VOTE ? !inner_trip : true;
+        if ( inner_trip ) {
+          if ( state == MRT_ST_INNER ) {
+            const uint32_t w0 = __float_as_uint( L0.x ), w1 = __float_as_uint( L0.y );
+            if ( ( w1 & 3u ) != 3u ) {
                 if ( STATS ) st.inner++;
-                const uint32_t axis = nd.y & 3u;
-                const float split   = __uint_as_float( nd.x );
-                const uint32_t left = nd.y >> 2;
-                const float diff    = split - comp( o, axis );
+                const uint32_t axis = w1 & 3u;
+                const uint32_t left = w1 >> 2;
+                const float diff    = L0.x - comp( o, axis );
                 const float t       = diff / comp( d, axis );
                 const bool lnear    = diff > 0.0f;
                 const uint32_t nr   = lnear ? left : left + 1;
                 const uint32_t fr   = lnear ? left + 1 : left;
-                if ( ( t > b ) || ( t < 0.0f ) ) { node = nr; }
-                else if ( t < a ) { node = fr; }
-                else {
-                    stack[sp++] = make_uint2( fr, __float_as_uint( b ) );
-                    node        = nr;
-                    b           = t;
-                }
-                nd = s.nodes[node];
-            }
-            if ( STATS ) st.leaves++;
-            // leaf: interval becomes [a, b]
-            float tmax         = b;
-            const uint32_t off = nd.x, cnt = nd.y >> 2;
-            bool has           = false;
-            float dist         = 0.f;
-            for ( uint32_t i = 0; i < cnt; i++ ) {
-                const uint32_t obj = s.refs[off + i];
-                if ( STATS ) {
-                    st.refs++;
-                    st.tests++;
-                }
-                DHit temp;
-                if ( prim_intersect( s, obj, o, d, a, tmax, xr, temp ) ) {
-                    if ( ANY ) {
-                        const uint32_t flags = __float_as_uint( s.prims[3 * (size_t)obj].w );
-                        if ( !( flags & MRT_PRIM_EMISSIVE ) ) {
-                            out = temp;
-                            return true;
-                        }
-                    }
+                node                = nr;
+                if ( !( ( t > b ) || ( t < 0.0f ) ) ) {
+                    if ( t < a ) { node = fr; }
                     else {
-                        const float temp_dist = tmax;
-                        if ( has ) {
-                            if ( temp_dist < dist ) {
-                                dist = temp_dist;
-                                out  = temp;
-                            }
-                        }
-                        else {
-                            has  = true;
-                            out  = temp;
-                            dist = temp_dist;
-                        }
+                        v2u e;
+                        e.x = fr, e.y = __float_as_uint( b );
+                        if ( sp < MRT_STACK_LDS ) stack_lds[sp * MRT_TRACE_BLOCK] = e;
+                        else stack_deep[sp - MRT_STACK_LDS] = e;
+                        sp++;
+                        b = t;
                     }
                 }
+                want_node = true;
             }
-            if ( has ) {
-                found = true;
-                break;
-            }
-            if ( sp == 0 ) break;
-            --sp;
-            node = stack[sp].x;
-            a    = b;
-            b    = __uint_as_float( stack[sp].y );
-        }
-    }
-
-    // ---- out-of-tree objects (kdtree.cpp:563-611): the backup ray is a closest-hit ray with the
-    // original interval
-    if ( s.n_out > 0 ) {
-        float btmax = found ? out.t : orig_tmax;
-        float dist  = found ? out.t : 0.f;
-        for ( uint32_t i = 0; i < s.n_out; i++ ) {
-            const uint32_t obj = s.out_of_tree[i];
-            if ( STATS ) st.tests++;
-            DHit temp;
-            if ( prim_intersect( s, obj, o, d, orig_tmin, btmax, xr, temp ) ) {
-                const float temp_dist = btmax;
-                if ( found ) {
-                    if ( temp_dist < dist ) {
-                        dist = temp_dist;
-                        out  = temp;
-                    }
-                }
+            else {
+                if ( STATS ) st.leaves++;
+                // leaf: the ray interval becomes [a, b]
+                tmax = b;
+                has  = false;
+                ptr  = w0;
+                end  = w0 + ( w1 >> 2 );
+                if ( ptr == end ) { pop = true; }
                 else {
-                    found = true;
-                    out   = temp;
-                    dist  = temp_dist;
-                    if ( ANY ) return true;
+                    want_refs = true;
+                    state     = MRT_ST_REFS;
                 }
             }
+          }
+        }
+        if ( leaf_trip ) {
+        if ( state == MRT_ST_REFS && !want_refs ) {
+            advance = true;
+            state   = MRT_ST_TEST;
+        }
+        else if ( state == MRT_ST_TEST ) {
+            if ( STATS ) {
+                st.refs++;
+                st.tests++;
+            }
+            const uint32_t flags = __float_as_uint( L0.w );
+            const uint32_t xf    = flags >> MRT_PRIM_XF_SHIFT;
+            if ( xf != xr_id ) {
+                V3 oo = o, od = d;
+                if ( xf != 0 ) transform_ray( s, xf_lds, xf, o, d, oo, od );
+                *xro_lds = mk4( oo.x, oo.y, oo.z, 0.f );
+                *xrd_lds = mk4( od.x, od.y, od.z, 0.f );
+                xr_id    = xf;
+            }
+            const v4f ro = *xro_lds, rd = *xrd_lds;
+            const V3 origin = mk3( ro.x, ro.y, ro.z ), dir = mk3( rd.x, rd.y, rd.z );
+            float t = 0.f, u = 0.f, v = 0.f, det = 0.f;
+            bool outside = true, hit;
+            if ( ( flags & 3u ) == MRT_PRIM_TRI ) {
+                hit     = tri_test( origin, dir, L0, L1, L2, a, tmax, t, u, v, det );
+                outside = !( det < 0.f );
+            }
+            else { hit = sphere_test( s, xf_lds, xf, origin, dir, o, d, a, tmax, t, outside ); }
+            if ( hit ) {
+                // accepted hits shrink the interval whether or not they are kept
+                const bool keep = ANY ? !( flags & MRT_PRIM_EMISSIVE ) : ( !has || t < tmax );
+                tmax            = t;
+                if ( keep ) {
+                    *out_lds = mk4( __uint_as_float( obj ), u, v, __uint_as_float( outside ? 1u : 0u ) );
+                    has      = true;
+                    if ( ANY ) retire = true;
+                }
+            }
+            ptr++;
+            if ( !retire ) {
+                if ( ptr < end ) advance = true;
+                else if ( has ) retire = true; // the search ends at the first leaf that produced a hit
+                else pop = true;
+            }
+        }
+        }
+        if ( pop ) {
+            if ( sp == 0 ) retire = true;
+            else {
+                --sp;
+                v2u e;
+                if ( sp < MRT_STACK_LDS ) e = stack_lds[sp * MRT_TRACE_BLOCK];
+                else e = stack_deep[sp - MRT_STACK_LDS];
+                a             = b;
+                b             = __uint_as_float( e.y );
+                node          = e.x;
+                want_node     = true;
+                state         = MRT_ST_INNER;
+            }
+        }
+        if ( retire ) {
+            // a shadow ray that found an occluder in the tree never reaches the planes
+            if ( STATS && !( ANY && has ) ) st.tests += pl_tests;
+            const v4f rec = *out_lds;
+            DHit h;
+            h.prim    = (int32_t)__float_as_uint( rec.x );
+            h.t       = has ? tmax : rec.w;
+            h.u       = rec.y;
+            h.v       = rec.z;
+            h.outside = has ? __float_as_uint( rec.w ) : 0u;
+            bool found = has;
+            if ( has_pl ) {
+                const v4f r = *pl_lds;
+                // a plane replaces a tree hit only if strictly nearer (never for an any-hit ray)
+                if ( !has || ( !ANY && r.y < h.t ) ) {
+                    h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
+                    found  = true;
+                }
+            }
+            io.store( tag, found, h );
+            state = MRT_ST_IDLE;
+        }
+        // ---------------------------------------------------------------- issue
+        if ( state == MRT_ST_FRESH ) {
+            state     = MRT_ST_INNER;
+            want_node = true;
+            node      = 0;
+        }
+        if ( want_refs ) {
+            next  = ld_ref( s, ptr );
+            next2 = ptr + 1 < end ? ld_ref( s, ptr + 1 ) : 0u;
+        }
+        if ( advance ) {
+            // the record of the next primitive and the reference two ahead go in flight
+            obj   = next;
+            next  = next2;
+            L0    = ld_prim( s, obj, 0 );
+            L1    = ld_prim( s, obj, 1 );
+            const float4 r2 = ld_prim( s, obj, 2 );
+            L2    = make_float2( r2.x, r2.y );
+            if ( ptr + 2 < end ) next2 = ld_ref( s, ptr + 2 );
+        }
+        if ( want_node ) {
+            const uint2 nd = ld_node( s, node );
+            L0.x           = __uint_as_float( nd.x );
+            L0.y           = __uint_as_float( nd.y );
         }
     }
-    if ( !found ) out.prim = -1;
-    return found;
+}
+
+// Adds the lanes' counters to stats[0..3]: one atomic per wave and counter.
+MRT_DEV void flush_stats( const DStats& st, unsigned long long* stats ) {
+    unsigned long long vals[4] = { st.inner, st.leaves, st.refs, st.tests };
+    for ( int k = 0; k < 4; k++ ) {
+        unsigned long long x = vals[k];
+        for ( int off = 32; off > 0; off >>= 1 )
+            x += __shfl_down( x, off );
+        if ( __lane_id() == 0 ) atomicAdd( &stats[k], x );
+    }
+}
+
+// Grid of a streaming traversal over n rays (n = upper bound when the count lives on the device):
+// as many blocks as the chip keeps resident for this kernel (the ray list is dealt statically to
+// the waves of the grid, so a block that had to wait for a slot would serialise its share), fewer
+// when the list is short.
+template <class Kernel>
+inline uint32_t trace_grid_blocks( Kernel kernel, uint64_t n, int n_cus ) {
+    static int per_cu = 0; // one per kernel instantiation
+    if ( per_cu == 0 ) {
+        int v = 0;
+        if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &v, kernel, MRT_TRACE_BLOCK, 0 ) != hipSuccess || v < 1 ) v = 1;
+        per_cu = v;
+    }
+    const uint64_t full = (uint64_t)n_cus * (uint64_t)per_cu;
+    const uint64_t want = ( n + MRT_TRACE_BLOCK - 1 ) / MRT_TRACE_BLOCK;
+    return (uint32_t)( want < full ? ( want ? want : 1u ) : full );
 }

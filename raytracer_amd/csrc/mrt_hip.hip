@@ -87,6 +87,7 @@ struct mrt_scene {
     RenderWorkspace ws;
     uint64_t* d_stats = nullptr; // 8 x u64 scratch for counters
     uint32_t tree_depth = 0;
+    int n_cus           = 256;
     bool has_camera     = false;
     ~mrt_scene();
 };
@@ -168,13 +169,18 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     uint32_t depth = 0;
     mrt_status vs  = validate_tree( d, &depth );
     if ( vs != MRT_OK ) return vs;
-    for ( uint32_t i = 0; i < d->n_out_of_tree; i++ )
+    for ( uint32_t i = 0; i < d->n_out_of_tree; i++ ) {
         if ( d->out_of_tree[i] >= d->n_objects ) return fail( MRT_ERR_INVALID, "out_of_tree index out of range" );
+        // kdtree.cpp:64: planes, and only planes, stay outside the tree
+        if ( d->obj_kind[d->out_of_tree[i]] != MRT_PLANE ) return fail( MRT_ERR_INVALID, "out_of_tree may list planes only" );
+    }
 
     int n_dev = 0;
     HIP_TRY( hipGetDeviceCount( &n_dev ) );
     if ( device < 0 || device >= n_dev ) return fail( MRT_ERR_DEVICE, "no such HIP device" );
     HIP_TRY( hipSetDevice( device ) );
+    int n_cus = 0;
+    HIP_TRY( hipDeviceGetAttribute( &n_cus, hipDeviceAttributeMultiprocessorCount, device ) );
 
     std::vector<float4> prims( 3 * (size_t)d->n_objects );
     for ( uint32_t i = 0; i < d->n_objects; i++ ) {
@@ -216,6 +222,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     std::unique_ptr<mrt_scene> s( new mrt_scene );
     s->device     = device;
     s->tree_depth = depth;
+    s->n_cus      = n_cus > 0 ? n_cus : 256;
     HIP_TRY( s->nodes.upload( nodes ) );
     HIP_TRY( s->refs.upload( std::vector<uint32_t>( d->refs, d->refs + d->n_refs ) ) );
     HIP_TRY( s->prims.upload( prims ) );
@@ -231,6 +238,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     t.out_of_tree = s->out_of_tree.p;
     t.n_nodes     = d->n_nodes;
     t.n_out       = d->n_out_of_tree;
+    t.n_xforms    = d->n_transforms;
     for ( int k = 0; k < 3; k++ ) {
         t.root_min[k] = d->root_min[k];
         t.root_max[k] = d->root_max[k];
@@ -253,42 +261,32 @@ void mrt_scene_destroy( mrt_scene* scene ) {
 // ------------------------------------------------------------------------------------------------
 // mrt_intersect
 // ------------------------------------------------------------------------------------------------
-template <bool ANY, bool STATS>
-__global__ void __launch_bounds__( 256 ) extend_batch_kernel( DTrace s,
-                                                              uint64_t n,
-                                                              const float* __restrict__ ox,
-                                                              const float* __restrict__ oy,
-                                                              const float* __restrict__ oz,
-                                                              const float* __restrict__ dx,
-                                                              const float* __restrict__ dy,
-                                                              const float* __restrict__ dz,
-                                                              const float* __restrict__ tmin,
-                                                              const float* __restrict__ tmax,
-                                                              int32_t* __restrict__ prim,
-                                                              float* __restrict__ t,
-                                                              float* __restrict__ u,
-                                                              float* __restrict__ v,
-                                                              unsigned long long* __restrict__ stats ) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    DStats st { 0, 0, 0, 0 };
-    if ( i < n ) {
-        DHit h;
-        trace_ray<ANY, STATS>( s, mk3( ox[i], oy[i], oz[i] ), mk3( dx[i], dy[i], dz[i] ), tmin[i], tmax[i], h, st );
+struct BatchIO {
+    const float *ox, *oy, *oz, *dx, *dy, *dz, *tmin, *tmax;
+    int32_t* prim;
+    float *t, *u, *v;
+    MRT_DEV void load( uint32_t i, uint32_t& tag, V3& o, V3& d, float& t0, float& t1 ) const {
+        tag = i;
+        o   = mk3( ox[i], oy[i], oz[i] );
+        d   = mk3( dx[i], dy[i], dz[i] );
+        t0  = tmin[i];
+        t1  = tmax[i];
+    }
+    MRT_DEV void store( uint32_t i, bool, const DHit& h ) const {
         prim[i] = h.prim;
         t[i]    = h.t;
         u[i]    = h.u;
         v[i]    = h.v;
     }
-    if ( STATS ) {
-        // one atomic per wave and counter
-        unsigned long long vals[4] = { st.inner, st.leaves, st.refs, st.tests };
-        for ( int k = 0; k < 4; k++ ) {
-            unsigned long long x = vals[k];
-            for ( int off = 32; off > 0; off >>= 1 )
-                x += __shfl_down( x, off );
-            if ( ( threadIdx.x & 63 ) == 0 ) atomicAdd( &stats[k], x );
-        }
-    }
+};
+
+template <bool ANY, bool STATS>
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK ) trace_batch_kernel( DTrace s, BatchIO io, uint32_t n, unsigned long long* __restrict__ stats ) {
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    lds_u32* lp = (lds_u32*)lds;
+    DStats st { 0, 0, 0, 0 };
+    trace_stream<ANY, false, STATS>( s, lp, io, n, st );
+    if ( STATS ) flush_stats( st, stats );
 }
 
 extern "C" mrt_status mrt_intersect( mrt_scene* sc,
@@ -306,7 +304,7 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
         if ( stats ) *stats = mrt_trace_stats {};
         return MRT_OK;
     }
-    if ( n > ( 1ull << 31 ) ) return fail( MRT_ERR_UNSUPPORTED, "batch larger than 2^31 rays" );
+    if ( n >= ( 1ull << 31 ) ) return fail( MRT_ERR_UNSUPPORTED, "batch larger than 2^31 rays" );
     const float* in[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmin, rays->tmax };
     for ( const float* p : in )
         if ( !p ) return fail( MRT_ERR_INVALID, "NULL ray array" );
@@ -341,10 +339,11 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
         dv    = hits->v;
     }
     if ( stats ) HIP_TRY( hipMemsetAsync( sc->d_stats, 0, 8 * sizeof( uint64_t ), stream ) );
-    const dim3 block( 256 ), grid( (unsigned)( ( n + 255 ) / 256 ) );
+    const dim3 block( MRT_TRACE_BLOCK );
     unsigned long long* ds = (unsigned long long*)sc->d_stats;
+    const BatchIO io { din[0], din[1], din[2], din[3], din[4], din[5], din[6], din[7], dprim, dt, du, dv };
 #define LAUNCH( A, S ) \
-    hipLaunchKernelGGL( ( extend_batch_kernel<A, S> ), grid, block, 0, stream, sc->trace, n, din[0], din[1], din[2], din[3], din[4], din[5], din[6], din[7], dprim, dt, du, dv, ds )
+    hipLaunchKernelGGL( ( trace_batch_kernel<A, S> ), dim3( trace_grid_blocks( trace_batch_kernel<A, S>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, ds )
     if ( flags == MRT_ANY_HIT ) {
         if ( stats ) LAUNCH( true, true );
         else LAUNCH( true, false );

@@ -1,0 +1,86 @@
+"""Times mrt_intersect on the ray classes of the benchmark frame (device-resident buffers).
+
+Scene: the bench.py scene (two stanford bunnies, plane floor).  Ray classes:
+  primary   camera rays, closest hit
+  bounce    rays leaving the primary hit points in random directions of the outgoing hemisphere
+            (closest hit) - the shape of the extend rays of bounce >= 1 and of the MIS rays
+  shadow    the same rays as any-hit queries with tmax 1e4 - the shape of the environment shadow rays
+
+usage: python tools/trace_bench.py [--reps N] [--layout L] [--small]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+from raytracer_amd import scenes  # noqa: E402
+from raytracer_amd.host import DeviceScene  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layout", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--mult", type=int, default=8, help="secondary rays per primary hit")
+    ap.add_argument("--small", action="store_true", help="69k-triangle single bunny instead of the bench scene")
+    a = ap.parse_args()
+    W, H = 1920, 1080
+    t0 = time.time()
+    sc = scenes.bunny_ibl(W, H, env=None) if a.small else scenes.bunny_pair(W, H, env=None)
+    tree = sc.initKdTree()
+    print("objects %d, tree (nodes, refs, depth) %s, build %.1fs" % (sc.n_objects, tree.counts(), time.time() - t0), flush=True)
+    flat = tree.flatten(a.layout)
+    dev = DeviceScene(flat)
+
+    from tests import orc
+    o, d = orc.camera_rays(flat.desc, W, H, seed=1)
+    n = len(o)
+    to = torch.from_numpy(np.ascontiguousarray(o)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(d)).cuda()
+    prim, t, u, v = dev.intersect(to, td, torch.zeros(n, device="cuda"), torch.full((n,), 1e5, device="cuda"))[:4]
+    hit = prim >= 0
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    sos, sds = [], []
+    for _ in range(a.mult):  # one "sample" after another, pixels in scanline order within each
+        w = torch.randn((n, 3), device="cuda", generator=g)
+        w = w / w.norm(dim=1, keepdim=True)
+        flip = (w * td).sum(1) > 0
+        w[flip] = -w[flip]
+        sos.append((to + t[:, None] * td + 1e-3 * w)[hit])
+        sds.append(w[hit])
+    so = torch.cat(sos).contiguous()
+    sd = torch.cat(sds).contiguous()
+    sets = (("primary", to, td, 1e5, False), ("bounce", so, sd, 1e5, False), ("shadow", so, sd, 1e4, True))
+    total_ms = 0.0
+    for name, oo, dd, far, any_hit in sets:
+        m = len(oo)
+        tmin = torch.zeros(m, device="cuda")
+        tmax = torch.full((m,), far, device="cuda")
+        p, _, _, _, st = dev.intersect(oo, dd, tmin, tmax, any_hit=any_hit, stats=True)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(a.reps):
+            dev.intersect(oo, dd, tmin, tmax, any_hit=any_hit)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / a.reps
+        total_ms += ms
+        b_ray = 52 + (8 * st.inner + 8 * st.leaves + 4 * st.refs + 36 * st.prim_tests) / m
+        digest = int((p.to(torch.int64) * torch.arange(1, m + 1, device="cuda") % 1000003).sum().item())
+        print("%-8s n=%d hits=%d  %.3f ms  %.1f Mrays/s | per ray: inner %.1f leaves %.2f refs %.2f tests %.2f  B_ray %.0f B -> %.1f GB/s  digest %d" % (
+            name, m, int((p >= 0).sum()), ms, m / ms / 1e3, st.inner / m, st.leaves / m, st.refs / m,
+            st.prim_tests / m, b_ray, b_ray * m / ms / 1e6, digest), flush=True)
+    print("total %.3f ms" % total_ms)
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()
