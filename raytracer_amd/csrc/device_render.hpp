@@ -72,16 +72,35 @@ struct RenderCounters {
     unsigned long long* c; // [0] closest rays, [1] any-hit rays
 };
 
-// Appends `id` to a queue for the lanes where `take` holds: one atomic per wave.
-MRT_DEV void queue_push( uint32_t* queue, uint32_t* counter, bool take, uint32_t id ) {
-    const unsigned long long mask = __ballot( take );
-    if ( mask == 0 ) return;
-    const uint32_t lane   = __lane_id();
-    const uint32_t leader = (uint32_t)__ffsll( (long long)mask ) - 1;
-    uint32_t base         = 0;
-    if ( lane == leader ) base = atomicAdd( counter, (uint32_t)__popcll( mask ) );
-    base = __shfl( base, leader );
-    if ( take ) queue[base + __popcll( mask & ( ( 1ull << lane ) - 1 ) )] = id;
+// Appends `id` to up to three queues for the threads whose `take[k]` holds.  Appends to one queue
+// all go through one counter, and same-address atomics are served one at a time by the memory
+// side (a frame makes tens of millions of appends), so the block first adds up its waves' counts
+// in LDS and reserves its range of each queue with a single atomic.  Every thread of the block
+// must call this.
+#define MRT_SHADE_BLOCK 1024
+MRT_DEV void queue_push3( uint32_t* const* queue, uint32_t* counters, const bool* take, uint32_t id ) {
+    __shared__ uint32_t s_cnt[3][MRT_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base[3];
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    unsigned long long mask[3];
+    for ( int k = 0; k < 3; k++ ) {
+        mask[k] = __ballot( take[k] );
+        if ( lane == 0 ) s_cnt[k][wave] = (uint32_t)__popcll( mask[k] );
+    }
+    __syncthreads();
+    if ( threadIdx.x < 3 ) {
+        const uint32_t k = threadIdx.x;
+        uint32_t sum     = 0;
+        for ( uint32_t w = 0; w < n_waves; w++ ) {
+            const uint32_t c = s_cnt[k][w];
+            s_cnt[k][w]      = sum;
+            sum += c;
+        }
+        s_base[k] = sum ? atomicAdd( counters + k, sum ) : 0u;
+    }
+    __syncthreads();
+    for ( int k = 0; k < 3; k++ )
+        if ( take[k] ) queue[k][s_base[k] + s_cnt[k][wave] + (uint32_t)__popcll( mask[k] & ( ( 1ull << lane ) - 1ull ) )] = id;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -131,7 +150,7 @@ struct ExtendIO {
     }
 };
 
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
     DStats st;
@@ -147,7 +166,7 @@ MRT_DEV void fold_pending( PathState& ps, uint32_t id, V3& L ) {
     ps.pending[id] = 0;
 }
 
-__global__ void __launch_bounds__( 256 ) shade_kernel( DTrace tr, DShade sh, PathState ps, PassInfo pi, Queues q, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t depth ) {
+__global__ void __launch_bounds__( MRT_SHADE_BLOCK ) shade_kernel( DTrace tr, DShade sh, PathState ps, PassInfo pi, Queues q, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t depth ) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = n_ptr ? *n_ptr : n_max;
     bool alive = false, has_shadow = false, has_mis = false;
@@ -280,9 +299,9 @@ __global__ void __launch_bounds__( 256 ) shade_kernel( DTrace tr, DShade sh, Pat
         }
         ps.Lx[id] = L.x, ps.Ly[id] = L.y, ps.Lz[id] = L.z;
     }
-    queue_push( q.next, q.counts + 0, alive, id );
-    queue_push( q.shadow, q.counts + 1, has_shadow, id );
-    queue_push( q.mis, q.counts + 2, has_mis, id );
+    uint32_t* const queues[3] = { q.next, q.shadow, q.mis };
+    const bool take[3]        = { alive, has_shadow, has_mis };
+    queue_push3( queues, q.counts, take, id );
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -303,7 +322,7 @@ struct ShadowIO {
     }
 };
 
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
     DStats st;
@@ -332,7 +351,7 @@ struct MisIO {
     }
 };
 
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
     DStats st;

@@ -40,9 +40,6 @@
 #ifndef MRT_REFILL_MIN
 #define MRT_REFILL_MIN 8 // idle lanes that trigger a refill of the wave
 #endif
-#ifndef MRT_VOTE
-#define MRT_VOTE 0
-#endif
 
 // prim record: 3 x float4
 //   q0 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane),
@@ -85,26 +82,26 @@ struct DStats {
 //   transform table   inv (9) + translation (3) of the first MRT_XF_LDS transforms
 //   stack             the first MRT_STACK_LDS deferred nodes of every lane (deeper ones in scratch)
 //   object-space ray  origin and direction under the lane's current transform
-//   hit record        the accepted hit of the current leaf (prim, u, v, outside); until there is
-//                     one, (-1, 0, 0, tmax the ray came with), which is what a miss reports
+//   hit record        the accepted hit of the current leaf (prim | outside << 31, u, v); until
+//                     there is one, the u slot keeps the tmax the ray came with, which is what a
+//                     miss reports as t
 //   plane record      the plane hit found when the ray was fetched (prim, t, u, v)
-#ifndef MRT_STACK_LDS
-#define MRT_STACK_LDS 6
-#endif
+#define MRT_STACK_LDS 5
 #define MRT_TRACE_BLOCK 256
 #define MRT_LDS_XF 0
 #define MRT_LDS_STACK ( MRT_LDS_XF + MRT_XF_LDS * 12 )
-#define MRT_LDS_XRO ( MRT_LDS_STACK + MRT_STACK_LDS * MRT_TRACE_BLOCK * 2 )
-#define MRT_LDS_XRD ( MRT_LDS_XRO + MRT_TRACE_BLOCK * 4 )
-#define MRT_LDS_OUT ( MRT_LDS_XRD + MRT_TRACE_BLOCK * 4 )
-#define MRT_LDS_PL ( MRT_LDS_OUT + MRT_TRACE_BLOCK * 4 )
+#define MRT_LDS_XR ( MRT_LDS_STACK + MRT_STACK_LDS * MRT_TRACE_BLOCK * 2 )  // 3 x float2 per lane
+#define MRT_LDS_OUT ( MRT_LDS_XR + 3 * MRT_TRACE_BLOCK * 2 )              // float2 + float per lane
+#define MRT_LDS_PL ( MRT_LDS_OUT + MRT_TRACE_BLOCK * 3 )                  // float4 per lane
 #define MRT_TRACE_LDS_WORDS ( MRT_LDS_PL + MRT_TRACE_BLOCK * 4 )
 
 typedef __attribute__( ( address_space( 3 ) ) ) uint32_t lds_u32;
 typedef __attribute__( ( address_space( 3 ) ) ) float lds_f32;
 typedef float v4f __attribute__( ( ext_vector_type( 4 ) ) );
 typedef uint32_t v2u __attribute__( ( ext_vector_type( 2 ) ) );
+typedef float v2f __attribute__( ( ext_vector_type( 2 ) ) );
 typedef __attribute__( ( address_space( 3 ) ) ) v4f lds_f4;
+typedef __attribute__( ( address_space( 3 ) ) ) v2f lds_f2;
 typedef __attribute__( ( address_space( 3 ) ) ) v2u lds_u2;
 MRT_DEV v4f mk4( float x, float y, float z, float w ) {
     v4f r;
@@ -261,9 +258,18 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     const lds_f32* xf_lds = (const lds_f32*)( lds + MRT_LDS_XF );
     stage_transforms( s, (lds_f32*)( lds + MRT_LDS_XF ) );
     lds_u2* stack_lds = (lds_u2*)( lds + MRT_LDS_STACK ) + threadIdx.x;
-    lds_f4* xro_lds   = (lds_f4*)( lds + MRT_LDS_XRO ) + threadIdx.x;
-    lds_f4* xrd_lds   = (lds_f4*)( lds + MRT_LDS_XRD ) + threadIdx.x;
-    lds_f4* out_lds   = (lds_f4*)( lds + MRT_LDS_OUT ) + threadIdx.x;
+    lds_f2* xr_lds    = (lds_f2*)( lds + MRT_LDS_XR ) + threadIdx.x;   // + k * MRT_TRACE_BLOCK, k = 0..2
+    lds_f2* out_lds   = (lds_f2*)( lds + MRT_LDS_OUT ) + threadIdx.x;  // (prim bits, u)
+    lds_f32* outv_lds = (lds_f32*)( lds + MRT_LDS_OUT + MRT_TRACE_BLOCK * 2 ) + threadIdx.x;
+    auto put_xr       = [&]( V3 ro, V3 rd ) {
+        v2f p;
+        p.x = ro.x, p.y = ro.y;
+        xr_lds[0] = p;
+        p.x = ro.z, p.y = rd.x;
+        xr_lds[MRT_TRACE_BLOCK] = p;
+        p.x = rd.y, p.y = rd.z;
+        xr_lds[2 * MRT_TRACE_BLOCK] = p;
+    };
     lds_f4* pl_lds    = (lds_f4*)( lds + MRT_LDS_PL ) + threadIdx.x;
 
     // Ray list shares: 64-ray chunks dealt round-robin to the waves of the grid; `taken` counts
@@ -304,9 +310,12 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                     float ray_tmin, ray_tmax;
                     io.load( idx, tag, o, d, ray_tmin, ray_tmax );
                     xr_id    = 0;
-                    *out_lds = mk4( __uint_as_float( 0xffffffffu ), 0.f, 0.f, ray_tmax );
-                    *xro_lds = mk4( o.x, o.y, o.z, 0.f );
-                    *xrd_lds = mk4( d.x, d.y, d.z, 0.f );
+                    {
+                        v2f m;
+                        m.x = __uint_as_float( 0xffffffffu ), m.y = ray_tmax;
+                        *out_lds = m;
+                    }
+                    put_xr( o, d );
                     // planes (kdtree.cpp:563-611), over the original interval: nearest one, the
                     // first on ties; an any-hit ray stops at the first accepted plane
                     has_pl      = false;
@@ -363,17 +372,9 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
 
         // ---------------------------------------------------------------- one step per lane
         // Compute first (this consumes the loads of the trip before), issue the next loads last.
-        // Only one kind of step runs per trip, the one more lanes are waiting for (a wave-uniform
-        // choice): every trip then costs the instructions of one branch instead of all of them,
-        // and the lanes of the other kind keep their loaded operands until their turn.
         bool pop = false, retire = false, advance = false, want_refs = false, want_node = false;
         uint32_t node = 0;
-        const uint32_t n_inner = (uint32_t)__popcll( __ballot( state == MRT_ST_INNER ) );
-        const uint32_t n_leaf  = (uint32_t)__popcll( __ballot( state == MRT_ST_REFS || state == MRT_ST_TEST ) );
-        const bool inner_trip  = MRT_VOTE ? n_inner >= n_leaf : true;
-        const bool leaf_trip   = MRT_VOTE ? !inner_trip : true;
-        if ( inner_trip ) {
-          if ( state == MRT_ST_INNER ) {
+        if ( state == MRT_ST_INNER ) {
             const uint32_t w0 = __float_as_uint( L0.x ), w1 = __float_as_uint( L0.y );
             if ( ( w1 & 3u ) != 3u ) {
                 if ( STATS ) st.inner++;
@@ -411,10 +412,8 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                     state     = MRT_ST_REFS;
                 }
             }
-          }
         }
-        if ( leaf_trip ) {
-        if ( state == MRT_ST_REFS && !want_refs ) {
+        else if ( state == MRT_ST_REFS ) {
             advance = true;
             state   = MRT_ST_TEST;
         }
@@ -428,12 +427,11 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             if ( xf != xr_id ) {
                 V3 oo = o, od = d;
                 if ( xf != 0 ) transform_ray( s, xf_lds, xf, o, d, oo, od );
-                *xro_lds = mk4( oo.x, oo.y, oo.z, 0.f );
-                *xrd_lds = mk4( od.x, od.y, od.z, 0.f );
-                xr_id    = xf;
+                put_xr( oo, od );
+                xr_id = xf;
             }
-            const v4f ro = *xro_lds, rd = *xrd_lds;
-            const V3 origin = mk3( ro.x, ro.y, ro.z ), dir = mk3( rd.x, rd.y, rd.z );
+            const v2f x0 = xr_lds[0], x1 = xr_lds[MRT_TRACE_BLOCK], x2 = xr_lds[2 * MRT_TRACE_BLOCK];
+            const V3 origin = mk3( x0.x, x0.y, x1.x ), dir = mk3( x1.y, x2.x, x2.y );
             float t = 0.f, u = 0.f, v = 0.f, det = 0.f;
             bool outside = true, hit;
             if ( ( flags & 3u ) == MRT_PRIM_TRI ) {
@@ -446,7 +444,10 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 const bool keep = ANY ? !( flags & MRT_PRIM_EMISSIVE ) : ( !has || t < tmax );
                 tmax            = t;
                 if ( keep ) {
-                    *out_lds = mk4( __uint_as_float( obj ), u, v, __uint_as_float( outside ? 1u : 0u ) );
+                    v2f m;
+                    m.x = __uint_as_float( obj | ( outside ? 0x80000000u : 0u ) ), m.y = u;
+                    *out_lds  = m;
+                    *outv_lds = v;
                     has      = true;
                     if ( ANY ) retire = true;
                 }
@@ -457,7 +458,6 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 else if ( has ) retire = true; // the search ends at the first leaf that produced a hit
                 else pop = true;
             }
-        }
         }
         if ( pop ) {
             if ( sp == 0 ) retire = true;
@@ -476,13 +476,13 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         if ( retire ) {
             // a shadow ray that found an occluder in the tree never reaches the planes
             if ( STATS && !( ANY && has ) ) st.tests += pl_tests;
-            const v4f rec = *out_lds;
+            const v2f rec = *out_lds;
             DHit h;
-            h.prim    = (int32_t)__float_as_uint( rec.x );
-            h.t       = has ? tmax : rec.w;
-            h.u       = rec.y;
-            h.v       = rec.z;
-            h.outside = has ? __float_as_uint( rec.w ) : 0u;
+            h.prim    = has ? (int32_t)( __float_as_uint( rec.x ) & 0x7fffffffu ) : -1;
+            h.t       = has ? tmax : rec.y;
+            h.u       = has ? rec.y : 0.f;
+            h.v       = has ? *outv_lds : 0.f;
+            h.outside = has ? __float_as_uint( rec.x ) >> 31 : 0u;
             bool found = has;
             if ( has_pl ) {
                 const v4f r = *pl_lds;
