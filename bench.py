@@ -189,22 +189,27 @@ def main():
         ext_bytes = b_ray(cts[0], int(cls_rays[0])) * float(cls_rays[0]) * scale
         con_bytes = (b_ray(cts[1], int(cls_rays[1])) * float(cls_rays[1]) + b_ray(cts[2], int(cls_rays[2])) * float(cls_rays[2])) * scale
         per_step = {k: v / args.steps for k, v in kms.items()}
+        n_bounces = MAX_DEPTH + 1
         if per_step["extend"] >= per_step["connect"]:
-            name, byts, ms = "extend_kernel", ext_bytes, per_step["extend"]
+            name, byts, ms, launches = "extend_kernel", ext_bytes, per_step["extend"], n_bounces
         else:
-            name, byts, ms = "connect_shadow_kernel+connect_mis_kernel", con_bytes, per_step["connect"]
+            name, byts, ms, launches = "connect_shadow_kernel+connect_mis_kernel", con_bytes, per_step["connect"], 2 * n_bounces
         achieved = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": name, "kernel_ms_per_step": ms,
-                "algorithmic_bytes_per_step": byts,
+                "traffic": None, "kernel": name, "launches_per_step": launches,
+                "avg_launch_ms": ms / launches, "algorithmic_bytes_per_launch": byts / launches,
                 "bytes_per_ray": {"extend": b_ray(cts[0], int(cls_rays[0])), "shadow": b_ray(cts[1], int(cls_rays[1])),
                                   "mis": b_ray(cts[2], int(cls_rays[2]))},
-                "note": "bytes per ray = 52 + 8*inner + 8*leaves + 4*refs + 36*prim_tests, counted by the CPU oracle on the sampled frame"}
+                "note": "bytes per ray = 52 + 8*inner + 8*leaves + 4*refs + 36*prim_tests, counted by the CPU oracle on the "
+                        "sampled frame; achieved = algorithmic bytes of the kernel's launches of one step / their summed "
+                        "HIP-event time; traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch from profiles/hbm_traffic.json"}
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof):
+        if os.path.exists(prof) and spp == 256 and world == 1:
             try:
                 with open(prof) as f:
-                    roof["traffic"] = json.load(f).get(name)
+                    per_step_bytes = json.load(f)["bytes_per_step"].get(name)
+                if per_step_bytes:
+                    roof["traffic"] = per_step_bytes / launches
             except Exception:
                 pass
     result["roofline"] = roof

@@ -26,13 +26,18 @@
 #pragma once
 #include "device_shading.hpp"
 
+// Rays and hits are 16-byte records (one or two wide loads/stores per path instead of up to
+// eight narrow ones, and whole 32-byte sectors used when the path ids of a wave are scattered);
+// everything else is one 32-bit array per field.
+//   ray records   r0 = (o.x, o.y, o.z, d.x)   r1 = (d.y, d.z, tmax, 0)
+//   hit record    (prim | outside << 31 as bits, or 0xffffffff for a miss; t; u; v)
 struct PathState {
-    // continuation ray (tmin = 0; tmax = 1e5 for camera rays, 1e4 afterwards)
-    float *ox, *oy, *oz, *dx, *dy, *dz;
-    // closest hit of the continuation ray
-    int32_t* h_prim;
-    float *h_t, *h_u, *h_v;
-    uint32_t* h_outside;
+    // continuation ray (tmin = 0; tmax = 1e5 for camera rays, 1e4 afterwards) and its closest hit
+    float4 *ray0, *ray1;
+    float4* hit;
+    // shadow ray (its contribution is already in di; cancelled if occluded) and MIS ray
+    float4 *sray0, *sray1;
+    float4 *mray0, *mray1;
     // path
     float *tpx, *tpy, *tpz; // throughput
     float *Lx, *Ly, *Lz;    // radiance so far
@@ -40,14 +45,33 @@ struct PathState {
     // pending direct lighting of the last shaded bounce: L += (ptp * di) / pick_pdf
     float *ptx, *pty, *ptz, *dix, *diy, *diz, *pick_pdf;
     uint32_t* pending;
-    // shadow ray + its contribution (already in di; cancelled if occluded)
-    float *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax;
-    // MIS ray + factors of its contribution
-    float *mox, *moy, *moz, *mdx, *mdy, *mdz;
+    // factors of the MIS ray's contribution
     float *mbx, *mby, *mbz, *mw, *mpdf;
     uint32_t* mlight;
 };
-#define MRT_PATH_WORDS 53
+#define MRT_PATH_WORDS 52
+
+MRT_DEV void put_ray( float4* r0, float4* r1, uint32_t id, V3 o, V3 d, float tmax ) {
+    r0[id] = make_float4( o.x, o.y, o.z, d.x );
+    r1[id] = make_float4( d.y, d.z, tmax, 0.f );
+}
+MRT_DEV void get_ray( const float4* r0, const float4* r1, uint32_t id, V3& o, V3& d, float& tmax ) {
+    const float4 a = r0[id], b = r1[id];
+    o    = mk3( a.x, a.y, a.z );
+    d    = mk3( a.w, b.x, b.y );
+    tmax = b.z;
+}
+MRT_DEV void put_hit( float4* hit, uint32_t id, const DHit& h ) {
+    const uint32_t bits = h.prim < 0 ? 0xffffffffu : ( (uint32_t)h.prim | ( h.outside ? 0x80000000u : 0u ) );
+    hit[id]             = make_float4( __uint_as_float( bits ), h.t, h.u, h.v );
+}
+MRT_DEV void get_hit( const float4* hit, uint32_t id, DHit& h ) {
+    const float4 r      = hit[id];
+    const uint32_t bits = __float_as_uint( r.x );
+    h.prim              = bits == 0xffffffffu ? -1 : (int32_t)( bits & 0x7fffffffu );
+    h.outside           = bits == 0xffffffffu ? 0u : bits >> 31;
+    h.t = r.y, h.u = r.z, h.v = r.w;
+}
 
 struct PassInfo {
     uint32_t width;
@@ -119,8 +143,7 @@ __global__ void __launch_bounds__( 256 ) generate_kernel( PathState ps, PassInfo
     V2 lens = strat2d( key, 1, sample, pi.spp_x, pi.spp_y );
     V3 o, d;
     camera_ray( cam, (float)x + jit.x, (float)y + jit.y, lens.x, lens.y, o, d );
-    ps.ox[id] = o.x, ps.oy[id] = o.y, ps.oz[id] = o.z;
-    ps.dx[id] = d.x, ps.dy[id] = d.y, ps.dz[id] = d.z;
+    put_ray( ps.ray0, ps.ray1, id, o, d, 100000.f );
     ps.tpx[id] = ps.tpy[id] = ps.tpz[id] = 1.f;
     ps.Lx[id] = ps.Ly[id] = ps.Lz[id] = 0.f;
     ps.rng_state[id] = rng.state;
@@ -133,21 +156,12 @@ __global__ void __launch_bounds__( 256 ) generate_kernel( PathState ps, PassInfo
 struct ExtendIO {
     PathState ps;
     const uint32_t* queue;
-    float tmax;
     MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
         id = queue ? queue[i] : i;
-        o  = mk3( ps.ox[id], ps.oy[id], ps.oz[id] );
-        d  = mk3( ps.dx[id], ps.dy[id], ps.dz[id] );
+        get_ray( ps.ray0, ps.ray1, id, o, d, t1 );
         t0 = 0.f;
-        t1 = tmax;
     }
-    MRT_DEV void store( uint32_t id, bool, const DHit& h ) const {
-        ps.h_prim[id]    = h.prim;
-        ps.h_t[id]       = h.t;
-        ps.h_u[id]       = h.u;
-        ps.h_v[id]       = h.v;
-        ps.h_outside[id] = h.outside;
-    }
+    MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
 };
 
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max ) {
@@ -176,19 +190,17 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK ) shade_kernel( DTrace tr, DS
         V3 L = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
         fold_pending( ps, id, L );
         V3 tp = mk3( ps.tpx[id], ps.tpy[id], ps.tpz[id] );
-        V3 ro = mk3( ps.ox[id], ps.oy[id], ps.oz[id] ), rd = mk3( ps.dx[id], ps.dy[id], ps.dz[id] );
+        V3 ro, rd;
+        float ray_far;
+        get_ray( ps.ray0, ps.ray1, id, ro, rd, ray_far );
         DHit h;
-        h.prim = ps.h_prim[id];
+        get_hit( ps.hit, id, h );
         if ( h.prim < 0 ) {
             // integrator.cpp:195-198
             if ( sh.env_light >= 0 ) L = L + tp * ibl_Le( sh, rd );
         }
         else {
-            h.t       = ps.h_t[id];
-            h.u       = ps.h_u[id];
-            h.v       = ps.h_v[id];
-            h.outside = ps.h_outside[id];
-            Surf sf   = surface_from_hit( tr, sh, ro, rd, h );
+            Surf sf = surface_from_hit( tr, sh, ro, rd, h );
             const DMaterial mat = sh.materials[sf.material];
             Pcg32 rng;
             rng.state = ps.rng_state[id];
@@ -251,9 +263,7 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK ) shade_kernel( DTrace tr, DS
                             float weight = power_heuristic( lightPdf, scatteringPdf );
                             di           = di + bsdf * Li * weight / lightPdf;
                             has_shadow   = true;
-                            ps.sox[id] = s_o.x, ps.soy[id] = s_o.y, ps.soz[id] = s_o.z;
-                            ps.sdx[id] = s_d.x, ps.sdy[id] = s_d.y, ps.sdz[id] = s_d.z;
-                            ps.stmax[id] = s_tmax;
+                            put_ray( ps.sray0, ps.sray1, id, s_o, s_d, s_tmax );
                         }
                     }
                     // integrator.cpp:97-99: `sample(..., &wi, ...) * max(dot(normal, wi), 0)` -- the
@@ -268,8 +278,7 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK ) shade_kernel( DTrace tr, DS
                             V3 m_o       = sf.position + ( wi * MRT_ACNE_EPS );
                             V3 m_d       = normalize3( wi );
                             has_mis      = true;
-                            ps.mox[id] = m_o.x, ps.moy[id] = m_o.y, ps.moz[id] = m_o.z;
-                            ps.mdx[id] = m_d.x, ps.mdy[id] = m_d.y, ps.mdz[id] = m_d.z;
+                            put_ray( ps.mray0, ps.mray1, id, m_o, m_d, 10000.f );
                             ps.mbx[id] = bsdf.x, ps.mby[id] = bsdf.y, ps.mbz[id] = bsdf.z;
                             ps.mw[id]     = weight;
                             ps.mpdf[id]   = scatteringPdf;
@@ -290,8 +299,7 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK ) shade_kernel( DTrace tr, DS
             if ( !( is_black( bsdf ) || pdf == 0.f ) ) {
                 if ( mat.type != 2 ) tp = tp * ( bsdf * fabsf( dot3( wi, sf.normal ) ) / pdf );
                 V3 no = sf.position + MRT_ACNE_EPS * wi;
-                ps.ox[id] = no.x, ps.oy[id] = no.y, ps.oz[id] = no.z;
-                ps.dx[id] = wi.x, ps.dy[id] = wi.y, ps.dz[id] = wi.z;
+                put_ray( ps.ray0, ps.ray1, id, no, wi, 10000.f );
                 ps.tpx[id] = tp.x, ps.tpy[id] = tp.y, ps.tpz[id] = tp.z;
                 alive = depth < pi.max_depth; // integrator.cpp:201
             }
@@ -311,10 +319,8 @@ struct ShadowIO {
     const uint32_t* queue;
     MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
         id = queue[i];
-        o  = mk3( ps.sox[id], ps.soy[id], ps.soz[id] );
-        d  = mk3( ps.sdx[id], ps.sdy[id], ps.sdz[id] );
+        get_ray( ps.sray0, ps.sray1, id, o, d, t1 );
         t0 = 0.f;
-        t1 = ps.stmax[id];
     }
     // integrator.cpp:88: `if (vis) Li = 0` -- the light term was the only term in DI so far
     MRT_DEV void store( uint32_t id, bool occluded, const DHit& ) const {
@@ -337,18 +343,10 @@ struct MisIO {
     const uint32_t* queue;
     MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
         id = queue[i];
-        o  = mk3( ps.mox[id], ps.moy[id], ps.moz[id] );
-        d  = mk3( ps.mdx[id], ps.mdy[id], ps.mdz[id] );
+        get_ray( ps.mray0, ps.mray1, id, o, d, t1 );
         t0 = 0.f;
-        t1 = 10000.f;
     }
-    MRT_DEV void store( uint32_t id, bool, const DHit& h ) const {
-        ps.h_prim[id]    = h.prim;
-        ps.h_t[id]       = h.t;
-        ps.h_u[id]       = h.u;
-        ps.h_v[id]       = h.v;
-        ps.h_outside[id] = h.outside;
-    }
+    MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
 };
 
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count ) {
@@ -363,12 +361,10 @@ __global__ void __launch_bounds__( 256 ) mis_resolve_kernel( DTrace tr, DShade s
     for ( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x ) {
         const uint32_t id = queue[i];
         DHit h;
-        h.prim    = ps.h_prim[id];
-        h.t       = ps.h_t[id];
-        h.u       = ps.h_u[id];
-        h.v       = ps.h_v[id];
-        h.outside = ps.h_outside[id];
-        const V3 o = mk3( ps.mox[id], ps.moy[id], ps.moz[id] ), d = mk3( ps.mdx[id], ps.mdy[id], ps.mdz[id] );
+        get_hit( ps.hit, id, h );
+        V3 o, d;
+        float far_unused;
+        get_ray( ps.mray0, ps.mray1, id, o, d, far_unused );
         const uint32_t li = ps.mlight[id];
         V3 Li             = mk3( 0.f );
         if ( h.prim >= 0 ) { // integrator.cpp:108-113
