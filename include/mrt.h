@@ -171,8 +171,10 @@ typedef struct mrt_rays {
     const float* tmax;
 } mrt_rays;
 
-/* Hit batch.  prim = object index or -1; t = Ray::tmax after the call; u,v = barycentric
- * weights of p2 and p3 for triangles (triangle.cpp:24-31), 0 otherwise. */
+/* Hit batch.  prim = object index or -1; t = hit distance (Ray::tmax after the call), or the
+ * tmax the ray came with when nothing was hit; u,v = barycentric weights of p2 and p3 for
+ * triangles (triangle.cpp:24-31), the unit-square coordinates of a plane hit (plane.cpp:25-26),
+ * 0 for spheres and misses. */
 typedef struct mrt_hits {
     int32_t* prim;
     float* t;

@@ -158,7 +158,10 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         return fail( MRT_ERR_INVALID, "object arrays are NULL" );
     if ( d->n_transforms == 0 || !d->transforms ) return fail( MRT_ERR_INVALID, "at least one transform (the identity, index 0) is required" );
     if ( d->n_materials == 0 || !d->materials ) return fail( MRT_ERR_INVALID, "at least one material is required" );
-    if ( d->n_objects >= ( 1u << 29 ) || d->n_transforms >= ( 1u << 28 ) ) return fail( MRT_ERR_UNSUPPORTED, "too many objects or transforms" );
+    // the kernels address the scene tables with 32-bit byte offsets, and a hit record keeps the
+    // object index in 31 bits
+    if ( d->n_objects >= ( 1u << 26 ) || d->n_transforms >= ( 1u << 26 ) ) return fail( MRT_ERR_UNSUPPORTED, "too many objects or transforms (limit 2^26)" );
+    if ( d->n_nodes >= ( 1u << 29 ) || d->n_refs >= ( 1u << 30 ) ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree too large (limits: 2^29 nodes, 2^30 leaf references)" );
     {
         static const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
         static const float zero[3]  = { 0, 0, 0 };

@@ -152,3 +152,62 @@ def test_device_buffers(small_bunny):
     hit = want["prim"] >= 0
     assert np.array_equal(_bits(t.cpu().numpy()[hit]), _bits(want["t"][hit]))
     dev.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 511, 4097])
+def test_ragged_batch_sizes(small_bunny, n):
+    """The ray list is dealt to the waves in 64-ray chunks and lanes are refilled in batches:
+    every list length, including those that leave most lanes of the last wave without a ray,
+    must produce exactly the per-ray results of the oracle."""
+    sc, tree = small_bunny
+    flat = tree.flatten(1)
+    dev = DeviceScene(flat)
+    o, d, tmin, tmax = _rays(flat, 64, 64, 3000, 21)
+    rng = np.random.default_rng(n)
+    pick = rng.choice(len(o), n, replace=False)
+    for any_hit in (False, True):
+        _compare(flat, dev, o[pick], d[pick], tmin[pick], tmax[pick], any_hit)
+    dev.close()
+
+
+def _many_transform_scene(n_spheres=150):
+    """More transforms than the traversal kernels stage in LDS (64): spheres and a few triangles,
+    each with its own scale/rotate/translate, over two planes."""
+    from raytracer_amd.host import Scene, Transform
+    rng = np.random.default_rng(5)
+    sc = Scene()
+    m = sc.CreateMaterial()
+    glow = sc.CreateMaterial(emission=(1, 1, 1))
+    for i in range(n_spheres):
+        t = Transform().scale(*(0.15 + 0.3 * rng.random(3))).rotate((0, 1, 0), float(rng.random() * 90))
+        t.translate(tuple(float(x) for x in (rng.random(3) * 8 - 4)))
+        sc.add_sphere(t, glow if i % 7 == 0 else m)
+    for i in range(40):
+        t = Transform().rotate((1, 0, 0), float(rng.random() * 180)).translate(tuple(float(x) for x in (rng.random(3) * 8 - 4)))
+        p = (rng.random(9) - 0.5).astype(np.float32)
+        sc.add_triangle(p, np.tile(np.array([0, 0, 1], np.float32), 3), (0, 0, 1), np.zeros(6, np.float32), t, m)
+    sc.add_plane(Transform().scale(9, 9, 1).rotate((1, 0, 0), -90).translate((0, -4.5, 0)), m)
+    sc.add_plane(Transform().scale(9, 9, 1).translate((0, 0, -5)), m)
+    sc.setSimpleCamera((0, 0, 12), (0, 0, 0), (0, 1, 0), 60.0, 96, 96, 0.0, 10.0)
+    return sc
+
+
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_many_transforms_two_planes(built, any_hit):
+    sc = _many_transform_scene()
+    tree = sc.initKdTree()
+    flat = tree.flatten(1)
+    assert flat.desc.contents.n_transforms > 64 and flat.desc.contents.n_out_of_tree == 2
+    dev = DeviceScene(flat)
+    o, d, tmin, tmax = _rays(flat, 96, 96, 40000, 31)
+    # rays that start outside the root box and point away from it must come back as misses or plane hits
+    far = np.tile(np.array([[50.0, 50.0, 50.0]], np.float32), (64, 1))
+    away = np.tile(np.array([[0.577, 0.577, 0.577]], np.float32), (64, 1))
+    o, d = np.concatenate([o, far]), np.concatenate([d, away])
+    tmin, tmax = np.concatenate([tmin, np.zeros(64, np.float32)]), np.concatenate([tmax, np.full(64, 1e5, np.float32)])
+    hits = _compare(flat, dev, o, d, tmin, tmax, any_hit)
+    assert hits > 10000
+    want, ws = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, any_hit, stats=True)
+    gs = dev.intersect(o, d, tmin, tmax, any_hit=any_hit, stats=True)[4]
+    assert (gs.inner, gs.leaves, gs.refs, gs.prim_tests) == (ws.inner, ws.leaves, ws.refs, ws.prim_tests)
+    dev.close()

@@ -216,6 +216,21 @@ def test_scene_create_rejects_malformed_descriptions(built):
         m[3] = d.n_materials
         d.obj_material = m
         return m
+    def sphere_out_of_tree(d):
+        # kdtree.cpp:64: only planes stay outside the tree
+        kinds = (C.c_uint32 * d.n_objects)()
+        C.memmove(kinds, d.obj_kind, C.sizeof(kinds))
+        oot = (C.c_uint32 * 1)(0)
+        d.out_of_tree, d.n_out_of_tree = oot, 1
+        return oot
+    st, msg, _ = try_create(sphere_out_of_tree)
+    assert st == 1 and "planes only" in msg
+
+    def too_many_nodes(d):
+        d.n_nodes = 1 << 29
+    st, msg, _ = try_create(too_many_nodes)
+    assert st == 4 and "too large" in msg
+
     st, msg, _ = try_create(bad_material)
     assert st in (1, 2)  # material check follows the device probe on a machine without a GPU
     assert lib.mrt_scene_create(None, 0, C.byref(h)) == 1
