@@ -143,19 +143,24 @@ MRT_DEV void transform_ray( const DTrace& s, const lds_f32* xf_lds, uint32_t xf,
 // Möller-Trumbore as shapes/triangle.cpp:4-40 evaluates it.  Returns true when the hit is accepted
 // into [tmin, tmax]; det is returned for the sidedness.
 MRT_DEV bool tri_test( V3 origin, V3 dir, float4 q0, float4 q1, float2 q2, float tmin, float tmax, float& t, float& u, float& v, float& det ) {
+    // Evaluated without early exits: in a wave whose lanes test unrelated triangles some lane
+    // always needs every term, and straight-line code spares the execution-mask bookkeeping of
+    // four nested returns.  The accept condition is the reference's chain of rejections, each
+    // negated as written (so a NaN passes the same tests it passes there).
     const V3 p1 = mk3( q0.x, q0.y, q0.z ), v1v2 = mk3( q1.x, q1.y, q1.z ), v1v3 = mk3( q1.w, q2.x, q2.y );
-    V3 c = cross3( dir, v1v3 );
-    det  = dot3( v1v2, c );
-    if ( det > -MRT_ACNE_EPS && det < MRT_ACNE_EPS ) return false;
-    float inv_det = 1.f / det;
-    V3 sv         = origin - p1;
-    u             = dot3( sv, c ) * inv_det;
-    if ( u < 0.f || u > 1.f ) return false;
-    V3 q = cross3( sv, v1v2 );
-    v    = dot3( dir, q ) * inv_det;
-    if ( v < 0.f || u + v > 1.f ) return false;
-    t = dot3( v1v3, q ) * inv_det;
-    return t >= tmin && t <= tmax;
+    const V3 c  = cross3( dir, v1v3 );
+    det         = dot3( v1v2, c );
+    const float inv_det = 1.f / det;
+    const V3 sv         = origin - p1;
+    u                   = dot3( sv, c ) * inv_det;
+    const V3 q          = cross3( sv, v1v2 );
+    v                   = dot3( dir, q ) * inv_det;
+    t                   = dot3( v1v3, q ) * inv_det;
+    const bool flat = ( det > -MRT_ACNE_EPS ) & ( det < MRT_ACNE_EPS );
+    const bool u_out = ( u < 0.f ) | ( u > 1.f );
+    const bool v_out = ( v < 0.f ) | ( u + v > 1.f );
+    const bool t_in  = ( t >= tmin ) & ( t <= tmax );
+    return !flat & !u_out & !v_out & t_in;
 }
 
 // Unit sphere in object space (shapes/sphere.cpp:52-133).  `wo`, `wd`: world ray (the one-root
@@ -372,52 +377,49 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
 
         // ---------------------------------------------------------------- one step per lane
         // Compute first (this consumes the loads of the trip before), issue the next loads last.
-        bool pop = false, retire = false, advance = false, want_refs = false, want_node = false;
-        uint32_t node = 0;
-        if ( state == MRT_ST_INNER ) {
+        // Written with selects instead of nested branches: in a wave of unrelated rays every
+        // branch is taken by some lane, so branching saves no arithmetic and costs scalar
+        // execution-mask bookkeeping for every level of nesting.
+        const bool is_inner = state == MRT_ST_INNER, is_test = state == MRT_ST_TEST;
+        bool advance = state == MRT_ST_REFS, retire = false, pop, want_refs, want_node;
+        uint32_t node;
+        {
             const uint32_t w0 = __float_as_uint( L0.x ), w1 = __float_as_uint( L0.y );
-            if ( ( w1 & 3u ) != 3u ) {
-                if ( STATS ) st.inner++;
-                const uint32_t axis = w1 & 3u;
-                const uint32_t left = w1 >> 2;
-                const float diff    = L0.x - comp( o, axis );
-                const float t       = diff / comp( d, axis );
-                const bool lnear    = diff > 0.0f;
-                const uint32_t nr   = lnear ? left : left + 1;
-                const uint32_t fr   = lnear ? left + 1 : left;
-                node                = nr;
-                if ( !( ( t > b ) || ( t < 0.0f ) ) ) {
-                    if ( t < a ) { node = fr; }
-                    else {
-                        v2u e;
-                        e.x = fr, e.y = __float_as_uint( b );
-                        if ( sp < MRT_STACK_LDS ) stack_lds[sp * MRT_TRACE_BLOCK] = e;
-                        else stack_deep[sp - MRT_STACK_LDS] = e;
-                        sp++;
-                        b = t;
-                    }
-                }
-                want_node = true;
+            const bool at_node = is_inner & ( ( w1 & 3u ) != 3u ), at_leaf = is_inner & ( ( w1 & 3u ) == 3u );
+            // inner node
+            const uint32_t axis = w1 & 3u;
+            const uint32_t left = w1 >> 2;
+            const float diff    = L0.x - comp( o, axis );
+            const float t       = diff / comp( d, axis );
+            const bool lnear    = diff > 0.0f;
+            const uint32_t nr   = lnear ? left : left + 1;
+            const uint32_t fr   = lnear ? left + 1 : left;
+            const bool near_only = ( t > b ) | ( t < 0.0f );
+            const bool far_only  = !near_only & ( t < a );
+            const bool both      = at_node & !near_only & !far_only;
+            node                 = far_only ? fr : nr;
+            want_node            = at_node;
+            if ( both ) {
+                v2u e;
+                e.x = fr, e.y = __float_as_uint( b );
+                if ( sp < MRT_STACK_LDS ) stack_lds[sp * MRT_TRACE_BLOCK] = e;
+                else stack_deep[sp - MRT_STACK_LDS] = e;
             }
-            else {
-                if ( STATS ) st.leaves++;
-                // leaf: the ray interval becomes [a, b]
-                tmax = b;
-                has  = false;
-                ptr  = w0;
-                end  = w0 + ( w1 >> 2 );
-                if ( ptr == end ) { pop = true; }
-                else {
-                    want_refs = true;
-                    state     = MRT_ST_REFS;
-                }
+            sp += both ? 1 : 0;
+            // leaf: the ray interval becomes [a, b]
+            tmax = at_leaf ? b : tmax;
+            b    = both ? t : b;
+            has  = has & !at_leaf;
+            ptr  = at_leaf ? w0 : ptr;
+            end  = at_leaf ? w0 + ( w1 >> 2 ) : end;
+            pop       = at_leaf & ( ptr == end );
+            want_refs = at_leaf & ( ptr != end );
+            if ( STATS ) {
+                st.inner += at_node ? 1u : 0u;
+                st.leaves += at_leaf ? 1u : 0u;
             }
         }
-        else if ( state == MRT_ST_REFS ) {
-            advance = true;
-            state   = MRT_ST_TEST;
-        }
-        else if ( state == MRT_ST_TEST ) {
+        if ( is_test ) {
             if ( STATS ) {
                 st.refs++;
                 st.tests++;
@@ -439,38 +441,36 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 outside = !( det < 0.f );
             }
             else { hit = sphere_test( s, xf_lds, xf, origin, dir, o, d, a, tmax, t, outside ); }
-            if ( hit ) {
-                // accepted hits shrink the interval whether or not they are kept
-                const bool keep = ANY ? !( flags & MRT_PRIM_EMISSIVE ) : ( !has || t < tmax );
-                tmax            = t;
-                if ( keep ) {
-                    v2f m;
-                    m.x = __uint_as_float( obj | ( outside ? 0x80000000u : 0u ) ), m.y = u;
-                    *out_lds  = m;
-                    *outv_lds = v;
-                    has      = true;
-                    if ( ANY ) retire = true;
-                }
+            // accepted hits shrink the interval whether or not they are kept
+            const bool keep = hit & ( ANY ? !( flags & MRT_PRIM_EMISSIVE ) : ( !has | ( t < tmax ) ) );
+            tmax            = hit ? t : tmax;
+            if ( keep ) {
+                v2f m;
+                m.x = __uint_as_float( obj | ( outside ? 0x80000000u : 0u ) ), m.y = u;
+                *out_lds  = m;
+                *outv_lds = v;
             }
+            has = has | keep;
             ptr++;
-            if ( !retire ) {
-                if ( ptr < end ) advance = true;
-                else if ( has ) retire = true; // the search ends at the first leaf that produced a hit
-                else pop = true;
-            }
+            // the search ends at the first leaf that produced a hit (a shadow ray: at the first hit)
+            const bool leaf_done = ptr >= end;
+            retire               = ANY ? ( keep | ( leaf_done & has ) ) : ( leaf_done & has );
+            advance              = !retire & !leaf_done;
+            pop                  = !retire & leaf_done;
         }
+        state = want_refs ? MRT_ST_REFS : ( ( advance & !is_test ) ? MRT_ST_TEST : state );
         if ( pop ) {
-            if ( sp == 0 ) retire = true;
-            else {
+            retire = sp == 0;
+            if ( sp != 0 ) {
                 --sp;
                 v2u e;
                 if ( sp < MRT_STACK_LDS ) e = stack_lds[sp * MRT_TRACE_BLOCK];
                 else e = stack_deep[sp - MRT_STACK_LDS];
-                a             = b;
-                b             = __uint_as_float( e.y );
-                node          = e.x;
-                want_node     = true;
-                state         = MRT_ST_INNER;
+                a         = b;
+                b         = __uint_as_float( e.y );
+                node      = e.x;
+                want_node = true;
+                state     = MRT_ST_INNER;
             }
         }
         if ( retire ) {

@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B of two builds of libmrt_hip.so on one box: raytracer_amd/ab/A.so and B.so, interleaved.
+cd $GRAFT_REPO_ROOT
+for rep in 1 2; do
+for v in A B; do
+  cp raytracer_amd/ab/$v.so raytracer_amd/libmrt_hip.so
+  timeout -k 10 200 python3 bench.py --steps 2 --warmup 1 --no-cpu 2>&1 | tail -1 | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read()); print('$v', round(r['value'],1), round(r['ms_per_step'],1), {k:round(x,1) for k,x in r['kernel_ms_per_step'].items()})" || exit 1
+done
+done
