@@ -1,8 +1,9 @@
 #!/bin/bash
-# A/B of two builds of libmrt_hip.so on one box: raytracer_amd/ab/A.so and B.so, interleaved.
+# A/B of builds of libmrt_hip.so on one box: raytracer_amd/ab/<name>.so for every name given, interleaved.
+# usage: tools/ab.sh A B [C ...]
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
-for v in A B; do
+for v in "$@"; do
   cp raytracer_amd/ab/$v.so raytracer_amd/libmrt_hip.so
   timeout -k 10 200 python3 bench.py --steps 2 --warmup 1 --no-cpu 2>&1 | tail -1 | python3 -c "
 import json,sys
