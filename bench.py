@@ -152,7 +152,8 @@ def main():
         "dtype": "f32",
         "data": "stanford-bunny.obj (69 451 triangles, x2 instances, vertices x20) + brown_photostudio_06_1k.hdr committed under assets/; camera, materials and floor synthetic",
         "config": {
-            "workload": "stanford-bunny diffuse+glossy, 1920x1080, 256 spp per GPU, max depth 5, HDR env (BASELINE configs[1])",
+            "workload": "stanford-bunny diffuse+glossy, 1920x1080, %d spp per GPU, max depth 5, HDR env (BASELINE configs[1]%s)" % (
+                spp, "" if spp == 256 else ", reduced spp for profiling"),
             "width": WIDTH, "height": HEIGHT, "spp_per_gpu": spp, "max_depth": MAX_DEPTH,
             "triangles": sc.n_objects - 1, "kd_nodes": n_nodes, "kd_refs": n_refs, "kd_depth": depth,
             "kd_build_s": round(build_s, 2), "parallelism": "sample-split x%d + RCCL reduce" % world if world > 1 else "single GPU",
@@ -169,8 +170,11 @@ def main():
     roof = None
     if not args.no_cpu:
         from tests import orc
-        cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-        cpu_s = max(1, min(args.cpu_spp, spp))
+        # the GPU box gives one GPU's share of the host: 16 cores (torchrun sets OMP_NUM_THREADS=1
+        # for its workers, so the thread count is passed to the oracle explicitly)
+        cores = min(os.cpu_count() or 1, 16)
+        # N > 1: no cpu_baseline line, only a 2-sample pass for the traversal counters of the roofline
+        cpu_s = max(1, min(args.cpu_spp if world == 1 else 2, spp))
         cp = render_params(WIDTH, HEIGHT, SPP_X, SPP_Y * world, max_depth=MAX_DEPTH, seed=SEED, sample_begin=0,
                            sample_end=cpu_s)
         tc = time.perf_counter()
@@ -183,6 +187,8 @@ def main():
         # relMSE of the GPU frame against the CPU sample is not meaningful at different spp; the
         # parity tests compare equal-spp renders.  Here only the mean radiance is cross-checked.
         cpu["mean_radiance"] = float(cimg.mean()) / cpu_s
+        if world > 1:
+            cpu = None
         # roofline of the dominant traversal kernel: algorithmic bytes / measured device time
         cls_rays = crs.class_rays
         scale = float(spp) / cpu_s  # the GPU step traces the same ray mix at 256 spp
