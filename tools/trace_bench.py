@@ -28,11 +28,12 @@ def main():
     ap.add_argument("--layout", type=int, default=1)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mult", type=int, default=8, help="secondary rays per primary hit")
+    ap.add_argument("--subdiv", type=int, default=0, help="midpoint subdivisions of the meshes (x4 triangles each)")
     ap.add_argument("--small", action="store_true", help="69k-triangle single bunny instead of the bench scene")
     a = ap.parse_args()
     W, H = 1920, 1080
     t0 = time.time()
-    sc = scenes.bunny_ibl(W, H, env=None) if a.small else scenes.bunny_pair(W, H, env=None)
+    sc = scenes.bunny_ibl(W, H, env=None, subdivisions=a.subdiv) if a.small else scenes.bunny_pair(W, H, env=None, subdivisions=a.subdiv)
     tree = sc.initKdTree()
     print("objects %d, tree (nodes, refs, depth) %s, build %.1fs" % (sc.n_objects, tree.counts(), time.time() - t0), flush=True)
     flat = tree.flatten(a.layout)
@@ -79,6 +80,15 @@ def main():
             name, m, int((p >= 0).sum()), ms, m / ms / 1e3, st.inner / m, st.leaves / m, st.refs / m,
             st.prim_tests / m, b_ray, b_ray * m / ms / 1e6, digest), flush=True)
     print("total %.3f ms" % total_ms)
+    # the same bounce batch handed over as host buffers (PCIe both ways inside the call)
+    ho, hd = so.cpu().numpy(), sd.cpu().numpy()
+    m = len(ho)
+    htmin, htmax = np.zeros(m, np.float32), np.full(m, 1e5, np.float32)
+    dev.intersect(ho, hd, htmin, htmax)
+    t0 = time.perf_counter()
+    dev.intersect(ho, hd, htmin, htmax)
+    dt = time.perf_counter() - t0
+    print("bounce, host buffers: %.1f ms  %.1f Mrays/s (copies included)" % (dt * 1e3, m / dt / 1e6))
     dev.close()
 
 
