@@ -101,7 +101,9 @@ struct RenderCounters {
 // side (a frame makes tens of millions of appends), so the block first adds up its waves' counts
 // in LDS and reserves its range of each queue with a single atomic.  Every thread of the block
 // must call this.
-#define MRT_SHADE_BLOCK 1024
+#ifndef MRT_SHADE_BLOCK
+#define MRT_SHADE_BLOCK 512
+#endif
 MRT_DEV void queue_push3( uint32_t* const* queue, uint32_t* counters, const bool* take, uint32_t id ) {
     __shared__ uint32_t s_cnt[3][MRT_SHADE_BLOCK / 64];
     __shared__ uint32_t s_base[3];
