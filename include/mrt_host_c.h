@@ -77,6 +77,7 @@ uint32_t mrth_flat_depth( void* flat );
 void mrth_flat_free( void* flat );
 
 /* HIPRenderer: init, run, destroy (mrt_host.hpp) */
+int mrth_intersect_kdtree( void* scene, void* tree, const float* o3, const float* d3, float tmin, float tmax, int shadow, float* out4 );
 int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, float* rgb_sum, mrt_render_stats* stats, double* seconds );
 
 #ifdef __cplusplus

@@ -170,6 +170,7 @@ def host():
             "mrth_flat_desc": (C.POINTER(SceneDesc), [vp]),
             "mrth_flat_depth": (C.c_uint32, [vp]),
             "mrth_flat_free": (None, [vp]),
+            "mrth_intersect_kdtree": (ci, [vp, vp, f32p, f32p, C.c_float, C.c_float, ci, f32p]),
             "mrth_hip_render": (ci, [vp, C.c_uint32, C.c_uint32, ci, ci, ci, C.c_uint32, ci, f32p,
                                      C.POINTER(RenderStats), C.POINTER(C.c_double)]),
         }

@@ -287,6 +287,24 @@ void mrth_flat_free( void* flat ) {
     delete static_cast<FlatScene*>( flat );
 }
 
+// bool intersectKdTree(Scene*, KdTree*, Ray*, Intersection*) for one ray.  out4 = prim, t, u, v.
+// Returns 1 on a hit, 0 on a miss, -1 on an error.
+int mrth_intersect_kdtree( void* scene, void* tree, const float* o3, const float* d3, float tmin, float tmax, int shadow, float* out4 ) {
+    int hit = 0;
+    int rc  = guarded( [&] {
+        Ray ray( point3( o3[0], o3[1], o3[2] ), vec3( d3[0], d3[1], d3[2] ), tmin, tmax );
+        ray.shadow = shadow != 0;
+        Intersection is;
+        hit     = intersectKdTree( static_cast<Scene*>( scene ), static_cast<KdTree*>( tree ), &ray, &is ) ? 1 : 0;
+        out4[0] = hit ? (float)is.prim : -1.f;
+        out4[1] = ray.tmax;
+        out4[2] = hit ? is.u : 0.f;
+        out4[3] = hit ? is.v : 0.f;
+        return 0;
+    } );
+    return rc < 0 ? -1 : hit;
+}
+
 // HIPRenderer::init + run + destroy; rgb_sum receives the linear radiance sums.
 int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, float* rgb_sum, mrt_render_stats* stats, double* seconds ) {
     return guarded( [&] {

@@ -155,6 +155,16 @@ class Scene:
     def initKdTree(self, n_threads=0):
         return KdTree(self, n_threads)
 
+    def hip_render(self, width, height, spp_x, spp_y, max_depth=5, seed=1, device=0):
+        """HIPRenderer::init + run + destroy (the GPU sibling of CPURenderer).  Returns the linear
+        radiance sums [h][w][3], the render statistics and the seconds run() took."""
+        img = np.zeros((height, width, 3), np.float32)
+        st, sec = abi.RenderStats(), C.c_double()
+        r = abi.host().mrth_hip_render(self._h, width, height, spp_x, spp_y, max_depth, seed, device, _fp(img), C.byref(st), C.byref(sec))
+        if r < 0:
+            raise MrtError(abi.host().mrth_last_error().decode())
+        return img, st, sec.value
+
 
 class KdTree:
     def __init__(self, scene, n_threads=0):
@@ -180,6 +190,15 @@ class KdTree:
 
     def flatten(self, layout=1):
         return FlatScene(self, layout)
+
+    def intersect(self, origin, direction, tmin=0.0, tmax=1e5, shadow=False):
+        """intersectKdTree for ONE ray through the C++ host API (a GPU round trip per call: for
+        debugging; batches go through DeviceScene.intersect).  Returns (prim or -1, t, u, v)."""
+        o, d, out = _f32(origin, 3), _f32(direction, 3), np.zeros(4, np.float32)
+        r = abi.host().mrth_intersect_kdtree(self.scene._h, self._h, _fp(o), _fp(d), tmin, tmax, 1 if shadow else 0, _fp(out))
+        if r < 0:
+            raise MrtError(abi.host().mrth_last_error().decode())
+        return int(out[0]), float(out[1]), float(out[2]), float(out[3])
 
 
 def tree_dump(call, nn, nr):

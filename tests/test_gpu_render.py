@@ -309,3 +309,27 @@ def test_full_size_frame_properties():
     want = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, False, threads=16)
     assert np.array_equal(prim, want["prim"])
     dev.close()
+
+
+def test_hip_renderer_and_single_ray_host_api():
+    """The C++ host classes that mirror the reference (HIPRenderer next to CPURenderer, and
+    intersectKdTree for one ray) give what the C-ABI gives directly."""
+    import torch
+    sc = scenes.cornell(48, 48)
+    img, st, seconds = sc.hip_render(48, 48, 2, 2, max_depth=4, seed=9)
+    tree = sc.initKdTree()
+    flat = tree.flatten(1)
+    dev = DeviceScene(flat)
+    direct = torch.zeros((48, 48, 3), dtype=torch.float32, device="cuda")
+    rs = dev.render(render_params(48, 48, 2, 2, max_depth=4, seed=9), direct)
+    assert np.array_equal(img, direct.cpu().numpy())
+    assert (st.rays_closest, st.rays_any, st.paths) == (rs.rays_closest, rs.rays_any, rs.paths) and seconds > 0
+    o, d = orc.camera_rays(flat.desc, 48, 48, seed=3)
+    tmin, tmax = np.zeros(len(o), np.float32), np.full(len(o), 1e5, np.float32)
+    want = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, False)
+    for i in range(0, len(o), 97):
+        prim, t, u, v = tree.intersect(o[i], d[i])
+        assert prim == want["prim"][i]
+        if prim >= 0:
+            assert np.float32(t) == want["t"][i]
+    dev.close()
