@@ -73,6 +73,15 @@ def test_environment_lit_mesh_with_plane():
     check_images(gpu, cpu, 16)
 
 
+def test_bench_scene_config2_reduced():
+    """BASELINE configs[1] exactly as bench.py builds it (two stanford bunnies under translations,
+    plane floor, the committed 1k HDR map, thin-lens camera) at reduced resolution and spp."""
+    gpu, cpu, rs, crs = render_both(scenes.bunny_pair(160, 90), 160, 90, 4, 2, 5, 1)
+    check_images(gpu, cpu, 8)
+    assert rs.paths == crs.paths == 160 * 90 * 8
+    assert abs(int(rs.rays_closest) - int(crs.rays_closest)) <= 1e-3 * crs.rays_closest
+
+
 def test_veach_mis_sphere_lights():
     """Scene 21: sphere emitters of very different size and radiance, plates of roughness .005-.1."""
     gpu, cpu, rs, crs = render_both(scenes.veach_mi(160, 90), 160, 90, 4, 4, 5, 21)
