@@ -67,7 +67,7 @@ def main():
     import numpy as np
     import torch
 
-    from raytracer_amd import scenes
+    from raytracer_amd import abi, scenes
     from raytracer_amd.host import DeviceScene, render_params
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,6 +101,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # one untimed frame with the traversal counters on: the node / leaf / reference / primitive-test
+    # visits the kernels really make, per ray class (rank 0 only, for the roofline)
+    own = None
+    if rank == 0:
+        params.flags = abi.MRT_RENDER_TRACE_STATS
+        own = step()
+        params.flags = 0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -191,9 +198,20 @@ def main():
             cpu = None
         # roofline of the dominant traversal kernel: algorithmic bytes / measured device time
         cls_rays = crs.class_rays
-        scale = float(spp) / cpu_s  # the GPU step traces the same ray mix at 256 spp
-        ext_bytes = b_ray(cts[0], int(cls_rays[0])) * float(cls_rays[0]) * scale
-        con_bytes = (b_ray(cts[1], int(cls_rays[1])) * float(cls_rays[1]) + b_ray(cts[2], int(cls_rays[2])) * float(cls_rays[2])) * scale
+        # reference-algorithm bytes (what the CPU traversal touches for the same rays) ...
+        ref_bytes_per_ray = {"extend": b_ray(cts[0], int(cls_rays[0])), "shadow": b_ray(cts[1], int(cls_rays[1])),
+                             "mis": b_ray(cts[2], int(cls_rays[2]))}
+        # ... and the bytes of the visits the kernels make themselves (fewer for shadow rays and, in a
+        # scene without emitters, MIS rays: a plane hit answers them without entering the tree and
+        # they stop at the first hit).  The roofline uses the kernels' own visits.
+        n_ext = float(own.rays_closest - own.rays_mis)
+        n_sh = float(own.rays_any)
+        n_mis = float(own.rays_mis)
+
+        def own_bytes(ts, n):
+            return 52.0 * n + 8.0 * ts.inner + 8.0 * ts.leaves + 4.0 * ts.refs + 36.0 * ts.prim_tests
+        ext_bytes = own_bytes(own.trace[0], n_ext)
+        con_bytes = own_bytes(own.trace[1], n_sh) + own_bytes(own.trace[2], n_mis)
         per_step = {k: v / args.steps for k, v in kms.items()}
         n_bounces = MAX_DEPTH + 1
         if per_step["extend"] >= per_step["connect"]:
@@ -204,11 +222,14 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "kernel": name, "launches_per_step": launches,
                 "avg_launch_ms": ms / launches, "algorithmic_bytes_per_launch": byts / launches,
-                "bytes_per_ray": {"extend": b_ray(cts[0], int(cls_rays[0])), "shadow": b_ray(cts[1], int(cls_rays[1])),
-                                  "mis": b_ray(cts[2], int(cls_rays[2]))},
-                "note": "bytes per ray = 52 + 8*inner + 8*leaves + 4*refs + 36*prim_tests, counted by the CPU oracle on the "
-                        "sampled frame; achieved = algorithmic bytes of the kernel's launches of one step / their summed "
-                        "HIP-event time; traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch from profiles/hbm_traffic.json"}
+                "bytes_per_ray": {"extend": ext_bytes / max(n_ext, 1.0), "shadow": own_bytes(own.trace[1], n_sh) / max(n_sh, 1.0),
+                                  "mis": own_bytes(own.trace[2], n_mis) / max(n_mis, 1.0)},
+                "reference_bytes_per_ray": ref_bytes_per_ray,
+                "note": "bytes per ray = 52 + 8*inner + 8*leaves + 4*refs + 36*prim_tests with the visits counted by the "
+                        "traversal kernels themselves on an untimed frame (reference_bytes_per_ray: the same formula on the "
+                        "CPU oracle's visits for the reference's traversal); achieved = those bytes of the kernel's launches "
+                        "of one step / their summed HIP-event time; traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch "
+                        "from profiles/hbm_traffic.json"}
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof) and spp == 256 and world == 1:
             try:

@@ -201,13 +201,22 @@ typedef struct mrt_render_params {
     uint32_t seed;                         /* replaces time(NULL) of CPURenderer.cpp:42 */
     uint32_t row_begin, row_end;           /* scanlines rendered by this call (tile split) */
     uint32_t paths_per_pass;               /* 0 = library default */
+    uint32_t flags;                        /* MRT_RENDER_* */
 } mrt_render_params;
+
+enum {
+    MRT_RENDER_TRACE_STATS = 1 /* count the traversal work of the call into mrt_render_stats.trace (slower kernels) */
+};
 
 typedef struct mrt_render_stats {
     uint64_t rays_closest; /* intersectKdTree-equivalent closest-hit queries */
     uint64_t rays_any;     /* shadow queries */
     uint64_t paths;        /* camera samples */
     double extend_ms, shade_ms, connect_ms, generate_ms; /* device time per kernel class */
+    /* with MRT_RENDER_TRACE_STATS: nodes, leaves, references and primitive tests the traversal
+     * kernels actually visited for [0] continuation rays, [1] shadow rays, [2] MIS rays */
+    mrt_trace_stats trace[3];
+    uint64_t rays_mis; /* the part of rays_closest that were MIS rays (integrator.cpp:104-109) */
 } mrt_render_stats;
 
 /* initKdTree + the Scene the reference hands to its integrator (kdtree.h:35, scene.h:19-43),

@@ -17,6 +17,7 @@ MRT_MAT_DIFFUSE, MRT_MAT_SPECULAR, MRT_MAT_TRANSPARENT = 0, 1, 2
 MRT_LIGHT_SHAPE, MRT_LIGHT_IBL = 0, 1
 MRT_BUF_HOST, MRT_BUF_DEVICE = 0, 1
 MRT_CLOSEST_HIT, MRT_ANY_HIT = 0, 1
+MRT_RENDER_TRACE_STATS = 1
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -87,12 +88,13 @@ class TraceStats(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "spp_x", "spp_y", "sample_begin", "sample_end",
-                                          "max_depth", "seed", "row_begin", "row_end", "paths_per_pass")]
+                                          "max_depth", "seed", "row_begin", "row_end", "paths_per_pass", "flags")]
 
 
 class RenderStats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("paths", C.c_uint64),
-                ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("connect_ms", C.c_double), ("generate_ms", C.c_double)]
+                ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("connect_ms", C.c_double), ("generate_ms", C.c_double),
+                ("trace", TraceStats * 3), ("rays_mis", C.c_uint64)]
 
 
 _hip = None

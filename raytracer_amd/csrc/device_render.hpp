@@ -166,11 +166,15 @@ struct ExtendIO {
     MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
 };
 
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max ) {
+// STATS (all traversal kernels of this file): also count the visited nodes, leaves, references
+// and primitive tests into stats[0..3].
+template <bool STATS>
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max, unsigned long long* __restrict__ stats ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
-    DStats st;
-    trace_stream<false, false, false>( tr, lp, io, n_ptr ? *n_ptr : n_max, st );
+    DStats st { 0, 0, 0, 0 };
+    trace_stream<false, false, STATS>( tr, lp, io, n_ptr ? *n_ptr : n_max, st );
+    if ( STATS ) flush_stats( st, stats );
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -330,11 +334,13 @@ struct ShadowIO {
     }
 };
 
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count ) {
+template <bool STATS>
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count, unsigned long long* __restrict__ stats ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
-    DStats st;
-    trace_stream<true, true, false>( tr, lp, io, *count, st );
+    DStats st { 0, 0, 0, 0 };
+    trace_stream<true, true, STATS>( tr, lp, io, *count, st );
+    if ( STATS ) flush_stats( st, stats );
 }
 
 // connect_mis: closest-hit traversal of the MIS rays.  The hit goes to the h_* arrays of the path
@@ -351,11 +357,42 @@ struct MisIO {
     MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
 };
 
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count ) {
+template <bool STATS>
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count, unsigned long long* __restrict__ stats ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
-    DStats st;
-    trace_stream<false, false, false>( tr, lp, io, *count, st );
+    DStats st { 0, 0, 0, 0 };
+    trace_stream<false, false, STATS>( tr, lp, io, *count, st );
+    if ( STATS ) flush_stats( st, stats );
+}
+
+// The same for a scene without a single emissive object.  Then the MIS ray only decides between
+// "hit something" (no radiance) and "escaped" (environment radiance), and whether the closest-hit
+// search of the reference finds a hit is exactly whether its shadow-ray search does (both accept a
+// primitive on the same closed leaf interval; they differ in what they do after the first accepted
+// hit and in skipping emissive primitives, of which there are none).  So the ray is traced with
+// shadow-ray semantics: it stops at the first hit and a plane hit spares the tree altogether.
+struct MisOcclusionIO {
+    PathState ps;
+    const uint32_t* queue;
+    MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
+        id = queue[i];
+        get_ray( ps.mray0, ps.mray1, id, o, d, t1 );
+        t0 = 0.f;
+    }
+    MRT_DEV void store( uint32_t id, bool found, const DHit& ) const {
+        // object 0 stands for "some non-emissive object"
+        ps.hit[id] = make_float4( __uint_as_float( found ? 0u : 0xffffffffu ), 0.f, 0.f, 0.f );
+    }
+};
+
+template <bool STATS>
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_mis_occlusion_kernel( DTrace tr, MisOcclusionIO io, const uint32_t* __restrict__ count, unsigned long long* __restrict__ stats ) {
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    lds_u32* lp = (lds_u32*)lds;
+    DStats st { 0, 0, 0, 0 };
+    trace_stream<true, true, STATS>( tr, lp, io, *count, st );
+    if ( STATS ) flush_stats( st, stats );
 }
 
 __global__ void __launch_bounds__( 256 ) mis_resolve_kernel( DTrace tr, DShade sh, PathState ps, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count ) {

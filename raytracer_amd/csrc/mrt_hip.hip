@@ -88,6 +88,7 @@ struct mrt_scene {
     uint64_t* d_stats = nullptr; // 8 x u64 scratch for counters
     uint32_t tree_depth = 0;
     int n_cus           = 256;
+    bool no_emitters    = false; // no object has a material with a non-zero emission component
     bool has_camera     = false;
     ~mrt_scene();
 };
@@ -185,6 +186,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     int n_cus = 0;
     HIP_TRY( hipDeviceGetAttribute( &n_cus, hipDeviceAttributeMultiprocessorCount, device ) );
 
+    bool no_emitters = true;
     std::vector<float4> prims( 3 * (size_t)d->n_objects );
     for ( uint32_t i = 0; i < d->n_objects; i++ ) {
         uint32_t kind = d->obj_kind[i], mat = d->obj_material[i], xf = d->obj_transform[i];
@@ -199,6 +201,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         // kdtree.cpp:533-534: a shadow ray ignores a hit iff all three emission components are non-zero-tested
         uint32_t emissive = !( e[0] == 0.f && e[1] == 0.f && e[2] == 0.f );
         uint32_t em_sum   = !( e[0] + e[1] + e[2] == 0.f );
+        if ( emissive || em_sum ) no_emitters = false;
         uint32_t flags    = k | ( emissive ? MRT_PRIM_EMISSIVE : 0u ) | ( em_sum ? MRT_PRIM_EMISSIVE_SUM : 0u ) | ( xf << MRT_PRIM_XF_SHIFT );
         const float* p    = d->tri_p + 9 * (size_t)i;
         float fl, fm;
@@ -226,6 +229,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     s->device     = device;
     s->tree_depth = depth;
     s->n_cus      = n_cus > 0 ? n_cus : 256;
+    s->no_emitters = no_emitters;
     HIP_TRY( s->nodes.upload( nodes ) );
     HIP_TRY( s->refs.upload( std::vector<uint32_t>( d->refs, d->refs + d->n_refs ) ) );
     HIP_TRY( s->prims.upload( prims ) );
