@@ -342,3 +342,28 @@ def test_hip_renderer_and_single_ray_host_api():
         if prim >= 0:
             assert np.float32(t) == want["t"][i]
     dev.close()
+
+
+def test_render_trace_counters():
+    """MRT_RENDER_TRACE_STATS: the traversal visits the render kernels count themselves agree with
+    the oracle's counters for the reference traversal where the kernels do the same walk
+    (continuation and MIS rays of a scene with emitters), and are fewer where they take a shortcut
+    (shadow rays stop at a plane hit without entering the tree)."""
+    sc = scenes.cornell(64, 64)
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    p = render_params(64, 64, 2, 2, max_depth=4, seed=3, flags=abi.MRT_RENDER_TRACE_STATS)
+    img = np.zeros((64, 64, 3), np.float32)
+    rs = dev.render(p, img)
+    cpu, crs, cts, _ = orc.oracle_render(flat.desc, p, 0, threads=8)
+    for cls in (0, 2):
+        for name in ("inner", "leaves", "refs", "prim_tests"):
+            g, c = getattr(rs.trace[cls], name), getattr(cts[cls], name)
+            assert abs(int(g) - int(c)) <= 2e-3 * c + 8, (cls, name, g, c)
+    assert 0 < rs.trace[1].inner <= cts[1].inner
+    assert rs.rays_mis == crs.class_rays[2] or abs(int(rs.rays_mis) - int(crs.class_rays[2])) <= 2e-3 * crs.class_rays[2]
+    # without the flag nothing is counted (and the frame is the same)
+    img2 = np.zeros((64, 64, 3), np.float32)
+    rs2 = dev.render(render_params(64, 64, 2, 2, max_depth=4, seed=3), img2)
+    assert rs2.trace[0].inner == 0 and np.array_equal(img, img2)
+    dev.close()
