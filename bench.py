@@ -104,7 +104,7 @@ def main():
     # one untimed frame with the traversal counters on: the node / leaf / reference / primitive-test
     # visits the kernels really make, per ray class (rank 0 only, for the roofline)
     own = None
-    if rank == 0:
+    if rank == 0 and not args.no_cpu:
         params.flags = abi.MRT_RENDER_TRACE_STATS
         own = step()
         params.flags = 0
@@ -217,7 +217,8 @@ def main():
         if per_step["extend"] >= per_step["connect"]:
             name, byts, ms, launches = "extend_kernel", ext_bytes, per_step["extend"], n_bounces
         else:
-            name, byts, ms, launches = "connect_shadow_kernel+connect_mis_kernel", con_bytes, per_step["connect"], 2 * n_bounces
+            # (the bench scene has no emissive object, so MIS rays go through the occlusion variant)
+            name, byts, ms, launches = "connect_shadow_kernel+connect_mis_occlusion_kernel", con_bytes, per_step["connect"], 2 * n_bounces
         achieved = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "kernel": name, "launches_per_step": launches,

@@ -40,7 +40,9 @@ def traffic(k):
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 0 --no-cpu`",
        "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, summed over the launches of one step",
        "bytes_per_step": {k: traffic(k) for k in pmc if "FETCH_SIZE" in pmc[k]}}
-out["bytes_per_step"]["connect_shadow_kernel+connect_mis_kernel"] = traffic("connect_shadow_kernel") + traffic("connect_mis_kernel")
+for mis in ("connect_mis_occlusion_kernel", "connect_mis_kernel"):  # whichever the scene made the library use
+    if mis in pmc:
+        out["bytes_per_step"]["connect_shadow_kernel+" + mis] = traffic("connect_shadow_kernel") + traffic(mis)
 out["fetch_size_kib_per_step"] = {k: pmc[k]["FETCH_SIZE"] for k in pmc if "FETCH_SIZE" in pmc[k]}
 out["write_size_kib_per_step"] = {k: pmc[k]["WRITE_SIZE"] for k in pmc if "WRITE_SIZE" in pmc[k]}
 with open(os.path.join(dst, "hbm_traffic.json"), "w") as f:

@@ -13,7 +13,7 @@ from collections import defaultdict
 
 def short(name):
     name = name.split("(")[0]
-    for k in ("extend_batch_kernel", "extend_kernel", "connect_shadow_kernel", "connect_mis_kernel", "shade_kernel",
+    for k in ("extend_batch_kernel", "extend_kernel", "connect_shadow_kernel", "connect_mis_occlusion_kernel", "connect_mis_kernel", "mis_resolve_kernel", "shade_kernel",
               "generate_kernel", "accumulate_kernel", "resolve_kernel"):
         if k in name:
             return k
