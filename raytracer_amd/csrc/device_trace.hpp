@@ -353,7 +353,10 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                         h.prim = 0, h.t = 0.f, h.u = h.v = 0.f, h.outside = 1;
                         io.store( tag, true, h );
                     }
-                    else if ( clip_root( s, o, d, ray_tmin, ray_tmax ) ) {
+                    // A ray with a NaN component takes the "visit both children" branch at every
+                    // node and fails every primitive test: the reference walks the whole tree to
+                    // find nothing.  Same result without the walk.
+                    else if ( !( isnan( o.x ) | isnan( o.y ) | isnan( o.z ) | isnan( d.x ) | isnan( d.y ) | isnan( d.z ) ) && clip_root( s, o, d, ray_tmin, ray_tmax ) ) {
                         a     = ray_tmin;
                         b     = ray_tmax;
                         sp    = 0;

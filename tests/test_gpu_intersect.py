@@ -211,3 +211,20 @@ def test_many_transforms_two_planes(built, any_hit):
     gs = dev.intersect(o, d, tmin, tmax, any_hit=any_hit, stats=True)[4]
     assert (gs.inner, gs.leaves, gs.refs, gs.prim_tests) == (ws.inner, ws.leaves, ws.refs, ws.prim_tests)
     dev.close()
+
+
+def test_nan_rays_do_not_stall(small_bunny):
+    """A ray with a NaN component can hit nothing in the tree (every comparison fails); the
+    reference finds that out by walking all of it, the kernels skip the walk.  Whatever the planes
+    report for such a ray is kept as the reference computes it."""
+    sc, tree = small_bunny
+    flat = tree.flatten(1)
+    dev = DeviceScene(flat)
+    o, d, tmin, tmax = _rays(flat, 32, 32, 1000, 41)
+    o, d = o.copy(), d.copy()
+    o[::7, 1] = np.nan
+    d[3::11, 0] = np.nan
+    want = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, False)
+    prim, t, u, v = dev.intersect(o, d, tmin, tmax)
+    assert np.array_equal(prim, want["prim"])
+    dev.close()
