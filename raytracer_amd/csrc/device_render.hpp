@@ -84,6 +84,25 @@ struct PassInfo {
     uint32_t max_depth;
 };
 
+// Pixel of the pass that path-local index p_local stands for.  When the pass is made of whole 8x8
+// tiles the pixels are numbered tile by tile, so that 64 consecutive paths (a wave's first rays, a
+// queue's neighbours) cover a square of the image instead of a 64-pixel line: their rays start
+// closer together and walk more of the same subtrees.  Otherwise scanline order.
+MRT_DEV void pass_pixel( const PassInfo& pi, uint32_t p_local, uint32_t& x, uint32_t& y ) {
+#ifndef MRT_NO_TILES
+    if ( ( ( pi.width | pi.n_rows ) & 7u ) == 0u ) {
+        const uint32_t tile = p_local >> 6, in = p_local & 63u, tiles_x = pi.width >> 3;
+        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        x = ( tx << 3 ) + ( in & 7u );
+        y = pi.row_begin + ( ty << 3 ) + ( in >> 3 );
+        return;
+    }
+#endif
+    const uint32_t r = p_local / pi.width;
+    x = p_local - r * pi.width;
+    y = pi.row_begin + r;
+}
+
 struct Queues {
     uint32_t* cur;     // live paths of this bounce
     uint32_t* next;    // survivors
@@ -134,7 +153,8 @@ __global__ void __launch_bounds__( 256 ) generate_kernel( PathState ps, PassInfo
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if ( id >= pi.n_paths ) return;
     const uint32_t s_local = id / pi.n_pixels, p_local = id - s_local * pi.n_pixels;
-    const uint32_t y = pi.row_begin + p_local / pi.width, x = p_local % pi.width;
+    uint32_t x, y;
+    pass_pixel( pi, p_local, x, y );
     const uint32_t pixel  = y * pi.width + x;
     const uint32_t sample = pi.sample_begin + s_local;
     const uint64_t key    = pixel_key( pi.seed, pixel );
@@ -212,7 +232,9 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK ) shade_kernel( DTrace tr, DS
             rng.state = ps.rng_state[id];
             rng.inc   = ps.rng_inc[id];
             const uint32_t s_local = id / pi.n_pixels, p_local = id - s_local * pi.n_pixels;
-            const uint32_t pixel  = ( pi.row_begin + p_local / pi.width ) * pi.width + p_local % pi.width;
+            uint32_t px, py;
+            pass_pixel( pi, p_local, px, py );
+            const uint32_t pixel = py * pi.width + px;
             const uint32_t sample = pi.sample_begin + s_local;
             const uint64_t key    = pixel_key( pi.seed, pixel );
 
@@ -439,7 +461,9 @@ __global__ void __launch_bounds__( 256 ) accumulate_kernel( PathState ps, PassIn
         fold_pending( ps, id, L );
         sum = sum + L;
     }
-    const uint32_t pixel = ( pi.row_begin + p / pi.width ) * pi.width + p % pi.width;
+    uint32_t px, py;
+    pass_pixel( pi, p, px, py );
+    const uint32_t pixel = py * pi.width + px;
     float* dst           = rgb_sum + 3 * (size_t)pixel;
     dst[0] += sum.x;
     dst[1] += sum.y;

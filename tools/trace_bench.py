@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mult", type=int, default=8, help="secondary rays per primary hit")
     ap.add_argument("--subdiv", type=int, default=0, help="midpoint subdivisions of the meshes (x4 triangles each)")
+    ap.add_argument("--tile", action="store_true", help="order the primary rays in 8x8 pixel tiles")
     ap.add_argument("--small", action="store_true", help="69k-triangle single bunny instead of the bench scene")
     a = ap.parse_args()
     W, H = 1920, 1080
@@ -41,6 +42,10 @@ def main():
 
     from tests import orc
     o, d = orc.camera_rays(flat.desc, W, H, seed=1)
+    if a.tile:
+        # 8x8 pixel tiles instead of scanlines: 64 consecutive rays cover a square, not a line
+        idx = np.arange(W * H).reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1)
+        o, d = o[idx], d[idx]
     n = len(o)
     to = torch.from_numpy(np.ascontiguousarray(o)).cuda()
     td = torch.from_numpy(np.ascontiguousarray(d)).cuda()
