@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mult", type=int, default=8, help="secondary rays per primary hit")
     ap.add_argument("--subdiv", type=int, default=0, help="midpoint subdivisions of the meshes (x4 triangles each)")
+    ap.add_argument("--octant", type=int, default=0, help="group secondary rays by direction octant within runs of this many rays")
     ap.add_argument("--tile", action="store_true", help="order the primary rays in 8x8 pixel tiles")
     ap.add_argument("--small", action="store_true", help="69k-triangle single bunny instead of the bench scene")
     a = ap.parse_args()
@@ -63,6 +64,13 @@ def main():
         sds.append(w[hit])
     so = torch.cat(sos).contiguous()
     sd = torch.cat(sds).contiguous()
+    if a.octant:
+        # within every run of a.octant consecutive rays, group the rays by the signs of their direction
+        m = len(so)
+        octant = ((sd[:, 0] < 0).long() | ((sd[:, 1] < 0).long() << 1) | ((sd[:, 2] < 0).long() << 2))
+        key = (torch.arange(m, device="cuda") // a.octant) * 8 + octant
+        order = torch.sort(key, stable=True).indices
+        so, sd = so[order].contiguous(), sd[order].contiguous()
     sets = (("primary", to, td, 1e5, False), ("bounce", so, sd, 1e5, False), ("shadow", so, sd, 1e4, True))
     total_ms = 0.0
     for name, oo, dd, far, any_hit in sets:
