@@ -106,7 +106,7 @@ def main():
     own = None
     if rank == 0 and not args.no_cpu:
         params.flags = abi.MRT_RENDER_TRACE_STATS
-        own = step()
+        own = dev.render(params, img, stream=stream)  # rank-local: no collective outside the steps all ranks run
         params.flags = 0
     if dist is not None:
         dist.barrier()
