@@ -74,11 +74,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
+    # MRT_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo, to rehearse the N > 1 control flow on
+    # a single-GPU box (RCCL refuses two ranks on one device); never set for measurements
+    rehearsal = os.environ.get("MRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     t0 = time.time()
     sc = scenes.bunny_pair(WIDTH, HEIGHT)
