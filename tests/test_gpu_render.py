@@ -367,3 +367,29 @@ def test_render_trace_counters():
     rs2 = dev.render(render_params(64, 64, 2, 2, max_depth=4, seed=3), img2)
     assert rs2.trace[0].inner == 0 and np.array_equal(img, img2)
     dev.close()
+
+
+def test_scene_without_a_tree():
+    """Only a plane under an environment: the kd-tree is empty and every ray is answered by the
+    out-of-tree plane list or the environment."""
+    from raytracer_amd.host import Scene, Transform
+    sc = Scene()
+    m = sc.CreateMaterial(roughness=0.7)
+    sc.add_plane(Transform().scale(5, 5, 1).rotate((1, 0, 0), -90), m)
+    sc.add_ibl_pixels(scenes.synthetic_env())
+    sc.setSimpleCamera((0, 2, 6), (0, 0, 0), (0, 1, 0), 60.0, 48, 48, 0.0, 5.0)
+    tree = sc.initKdTree()
+    assert tree.counts() == (0, 0, 0)
+    flat = tree.flatten(1)
+    dev = DeviceScene(flat)
+    o, d = orc.camera_rays(flat.desc, 48, 48, seed=2)
+    tmin, tmax = np.zeros(len(o), np.float32), np.full(len(o), 1e5, np.float32)
+    for any_hit in (False, True):
+        want = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, any_hit)
+        prim, t, u, v = dev.intersect(o, d, tmin, tmax, any_hit=any_hit)
+        assert np.array_equal(prim, want["prim"]) and (prim >= 0).any() and (prim < 0).any()
+        hit = prim >= 0
+        assert np.array_equal(t[hit].view(np.uint32), want["t"][hit].view(np.uint32))
+    dev.close()
+    gpu, cpu, rs, crs = render_both(sc, 48, 48, 2, 2, 4, 17)
+    check_images(gpu, cpu, 4)
