@@ -189,7 +189,7 @@ struct ExtendIO {
 // STATS (all traversal kernels of this file): also count the visited nodes, leaves, references
 // and primitive tests into stats[0..3].
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max, unsigned long long* __restrict__ stats ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
@@ -357,7 +357,7 @@ struct ShadowIO {
 };
 
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count, unsigned long long* __restrict__ stats ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
@@ -380,7 +380,7 @@ struct MisIO {
 };
 
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count, unsigned long long* __restrict__ stats ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
@@ -409,7 +409,7 @@ struct MisOcclusionIO {
 };
 
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, 6 ) connect_mis_occlusion_kernel( DTrace tr, MisOcclusionIO io, const uint32_t* __restrict__ count, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_occlusion_kernel( DTrace tr, MisOcclusionIO io, const uint32_t* __restrict__ count, unsigned long long* __restrict__ stats ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };

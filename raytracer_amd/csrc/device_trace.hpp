@@ -36,7 +36,9 @@
 
 #define MRT_STACK_MAX 64
 #define MRT_ACNE_EPS 1e-4f
-#define MRT_XF_LDS 64          // transforms kept in LDS (12 floats each); the rest are read from HBM
+#ifndef MRT_XF_LDS
+#define MRT_XF_LDS 64 // transforms kept in LDS (12 floats each); the rest are read from HBM
+#endif
 #ifndef MRT_REFILL_MIN
 #define MRT_REFILL_MIN 8 // idle lanes that trigger a refill of the wave
 #endif
@@ -86,8 +88,13 @@ struct DStats {
 //                     there is one, the u slot keeps the tmax the ray came with, which is what a
 //                     miss reports as t
 //   plane record      the plane hit found when the ray was fetched (prim, t, u, v)
+#ifndef MRT_STACK_LDS
 #define MRT_STACK_LDS 5
+#endif
 #define MRT_TRACE_BLOCK 256
+#ifndef MRT_TRACE_WAVES
+#define MRT_TRACE_WAVES 6 // waves per SIMD the traversal kernels are compiled for (register budget)
+#endif
 #define MRT_LDS_XF 0
 #define MRT_LDS_STACK ( MRT_LDS_XF + MRT_XF_LDS * 12 )
 #define MRT_LDS_XR ( MRT_LDS_STACK + MRT_STACK_LDS * MRT_TRACE_BLOCK * 2 )  // 3 x float2 per lane

@@ -228,3 +228,21 @@ def test_nan_rays_do_not_stall(small_bunny):
     prim, t, u, v = dev.intersect(o, d, tmin, tmax)
     assert np.array_equal(prim, want["prim"])
     dev.close()
+
+
+def test_million_triangle_scene(built):
+    """BASELINE configs[2] size class: the stanford bunny subdivided twice (1.1 M triangles,
+    24 M nodes, 60 M leaf references, depth 51): table offsets beyond 2^28 bytes, a working set
+    larger than the on-chip caches.  Sub-epsilon triangles (the reference's absolute |det| test
+    hides most of them) are part of the parity."""
+    sc = scenes.bunny_ibl(256, 144, env=None, subdivisions=2)
+    tree = sc.initKdTree()
+    nn, nr, depth = tree.counts()
+    assert nn > 20_000_000 and nr > 50_000_000 and depth <= 62
+    flat = tree.flatten(1)
+    dev = DeviceScene(flat)
+    o, d, tmin, tmax = _rays(flat, 256, 144, 60000, 51)
+    for any_hit in (False, True):
+        hits = _compare(flat, dev, o, d, tmin, tmax, any_hit)
+        assert hits > 1000
+    dev.close()
