@@ -78,6 +78,23 @@ def bunny_pair(width=1920, height=1080, env="brown_photostudio_06_1k.hdr", subdi
     return sc
 
 
+def million_bunny(width=1920, height=1080, env="brown_photostudio_06_1k.hdr"):
+    """BASELINE config 3 size class (the reference's dragon.obj is not available): the stanford
+    bunny subdivided twice, 1 111 216 triangles.  Everything is four times the size of bunny_ibl so
+    that the subdivided triangles stay clear of the absolute |det| < 1e-4 rejection."""
+    sc = Scene()
+    frm, at = (-1.2, 10.4, 24.0), (-1.2, 8.0, 0.0)
+    focus = float(np.linalg.norm(np.array(at, np.float32) - np.array(frm, np.float32)).astype(np.float32))
+    sc.setSimpleCamera(frm, at, (0, 1, 0), 60, width, height, 0.08, focus)
+    if env:
+        sc.add_ibl_file(asset(env), also_env=True)
+    floor = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(0.6, 0.6, 0.6), metalness=0.0, roughness=0.8)
+    sc.add_plane(Transform().scale(32, 32, 1).rotate((-1, 0, 0), 90).translate((0, 2.64, 0)), floor)
+    body = sc.CreateMaterial(abi.MRT_MAT_SPECULAR, albedo=(1, 1, 1), roughness=0.2, metalness=0.9)
+    sc.addObjectsFromFile(asset("stanford-bunny.obj"), body, Transform(), prescale=80.0, subdivisions=2)
+    return sc
+
+
 def small_bunny(width=256, height=256, env_pixels=None, with_floor=True):
     """bunny.obj (4 968 triangles, about 1.5 units tall): the quick parity scene."""
     sc = Scene()
