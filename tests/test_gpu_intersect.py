@@ -232,10 +232,11 @@ def test_nan_rays_do_not_stall(small_bunny):
 
 def test_million_triangle_scene(built):
     """BASELINE configs[2] size class: the stanford bunny subdivided twice (1.1 M triangles,
-    24 M nodes, 60 M leaf references, depth 51): table offsets beyond 2^28 bytes, a working set
-    larger than the on-chip caches.  Sub-epsilon triangles (the reference's absolute |det| test
-    hides most of them) are part of the parity."""
-    sc = scenes.bunny_ibl(256, 144, env=None, subdivisions=2)
+    26 M nodes, 64 M leaf references, depth 53): table offsets beyond 2^28 bytes, a working set
+    larger than the on-chip caches.  Rays and a small frame against the oracle."""
+    from raytracer_amd.host import render_params
+    sc = scenes.million_bunny(256, 144, env=None)
+    sc.add_ibl_pixels(scenes.synthetic_env())
     tree = sc.initKdTree()
     nn, nr, depth = tree.counts()
     assert nn > 20_000_000 and nr > 50_000_000 and depth <= 62
@@ -244,5 +245,11 @@ def test_million_triangle_scene(built):
     o, d, tmin, tmax = _rays(flat, 256, 144, 60000, 51)
     for any_hit in (False, True):
         hits = _compare(flat, dev, o, d, tmin, tmax, any_hit)
-        assert hits > 1000
+        assert hits > 20000
+    p = render_params(256, 144, 2, 2, max_depth=4, seed=5)
+    gpu = np.zeros((144, 256, 3), np.float32)
+    dev.render(p, gpu)
+    cpu = orc.oracle_render(flat.desc, p, 0, threads=16)[0]
+    rel_mse = float(np.mean((gpu / 4 - cpu / 4) ** 2 / ((cpu / 4) ** 2 + 1e-2)))
+    assert rel_mse <= 1e-5, rel_mse
     dev.close()
