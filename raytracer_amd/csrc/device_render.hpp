@@ -122,6 +122,9 @@ struct RenderCounters {
 // must call this.
 #ifndef MRT_SHADE_BLOCK
 #define MRT_SHADE_BLOCK 512
+#ifndef MRT_SHADE_WAVES
+#define MRT_SHADE_WAVES 4 // waves per SIMD the shade kernel is compiled for
+#endif
 #endif
 MRT_DEV void queue_push3( uint32_t* const* queue, uint32_t* counters, const bool* take, uint32_t id ) {
     __shared__ uint32_t s_cnt[3][MRT_SHADE_BLOCK / 64];
@@ -206,7 +209,7 @@ MRT_DEV void fold_pending( PathState& ps, uint32_t id, V3& L ) {
     ps.pending[id] = 0;
 }
 
-__global__ void __launch_bounds__( MRT_SHADE_BLOCK ) shade_kernel( DTrace tr, DShade sh, PathState ps, PassInfo pi, Queues q, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t depth ) {
+__global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kernel( DTrace tr, DShade sh, PathState ps, PassInfo pi, Queues q, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t depth ) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = n_ptr ? *n_ptr : n_max;
     bool alive = false, has_shadow = false, has_mis = false;
