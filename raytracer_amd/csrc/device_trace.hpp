@@ -21,7 +21,7 @@
 //     any-hit rays the first accepted plane) and merged with the tree result when the ray retires.
 //
 // Execution model: streaming traversal.  A wave owns an interleaved share of the ray list and every
-// lane is a small state machine (idle / inner / leaf references / primitive test).  One trip of
+// lane is a small state machine (idle / node / primitive test).  One trip of
 // the wave's loop performs, for every lane, the work that depends on the loads issued in the trip
 // before and issues the next loads, so a trip costs one memory round trip however the lanes'
 // states are mixed; lanes whose ray retired are refilled from the wave's share once enough of
@@ -49,6 +49,10 @@
 //   q2 = e2.yz  , material , 0      bit 3 emission.r+g+b != 0 (isBlack, integrator.cpp:110),
 //                                   bits 4.. transform index (0 = identity)
 //   e1 = p2 - p1, e2 = p3 - p1 (fp32, as triangle.cpp:9-10)
+// Device node record, 16 bytes.  An inner node uses the first 8 (split bits, axis | left << 2; its
+// children are adjacent, right = left + 1); a leaf is (first reference, 3 | count << 2, reference 0,
+// reference 1): its first two references arrive with the node itself, so no trip is spent waiting
+// for them.  Further references come from the reference list.
 #define MRT_PRIM_TRI 0u
 #define MRT_PRIM_SPHERE 1u
 #define MRT_PRIM_PLANE 2u
@@ -57,7 +61,7 @@
 #define MRT_PRIM_XF_SHIFT 4
 
 struct DTrace {
-    const uint2* nodes;
+    const uint4* nodes;
     const uint32_t* refs;
     const float4* prims;
     const DXf* xforms;
@@ -242,14 +246,13 @@ MRT_DEV bool clip_root( const DTrace& s, V3 o, V3 d, float& ray_tmin, float& ray
 // Lane states of the streaming traversal.
 #define MRT_ST_IDLE 0u  // no ray
 #define MRT_ST_INNER 1u // node record in flight
-#define MRT_ST_REFS 2u  // first two leaf references in flight
 #define MRT_ST_TEST 3u  // record of the current primitive in flight
 #define MRT_ST_FRESH 4u // fetched in this trip: the root node goes in flight at its end
 
 // Byte-offset loads: tables are addressed as base + 32-bit byte offset (checked at scene creation),
 // which the hardware forms from a scalar base and one vector register.
-MRT_DEV uint2 ld_node( const DTrace& s, uint32_t node ) {
-    return *(const uint2*)( (const char*)s.nodes + ( node << 3 ) );
+MRT_DEV uint4 ld_node( const DTrace& s, uint32_t node ) {
+    return *(const uint4*)( (const char*)s.nodes + ( node << 4 ) );
 }
 MRT_DEV uint32_t ld_ref( const DTrace& s, uint32_t i ) {
     return *(const uint32_t*)( (const char*)s.refs + ( i << 2 ) );
@@ -295,7 +298,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     uint32_t tag   = 0;
     V3 o = mk3( 0.f ), d = mk3( 0.f );
     float a = 0.f, b = 0.f, tmax = 0.f;
-    // Load registers: (L0.x, L0.y) is the node record in state INNER; L0, L1, L2 the primitive
+    // Load registers: L0 is the node record in state INNER; L0, L1, L2 the primitive
     // record in state TEST.
     float4 L0 = make_float4( 0.f, 0.f, 0.f, 0.f ), L1 = L0;
     float2 L2 = make_float2( 0.f, 0.f );
@@ -391,7 +394,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         // branch is taken by some lane, so branching saves no arithmetic and costs scalar
         // execution-mask bookkeeping for every level of nesting.
         const bool is_inner = state == MRT_ST_INNER, is_test = state == MRT_ST_TEST;
-        bool advance = state == MRT_ST_REFS, retire = false, pop, want_refs, want_node;
+        bool advance = false, retire = false, pop, want_node;
         uint32_t node;
         {
             const uint32_t w0 = __float_as_uint( L0.x ), w1 = __float_as_uint( L0.y );
@@ -423,7 +426,9 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             ptr  = at_leaf ? w0 : ptr;
             end  = at_leaf ? w0 + ( w1 >> 2 ) : end;
             pop       = at_leaf & ( ptr == end );
-            want_refs = at_leaf & ( ptr != end );
+            advance   = at_leaf & ( ptr != end ); // the first record goes in flight in this trip
+            next      = at_leaf ? __float_as_uint( L0.z ) : next;
+            next2     = at_leaf ? __float_as_uint( L0.w ) : next2;
             if ( STATS ) {
                 st.inner += at_node ? 1u : 0u;
                 st.leaves += at_leaf ? 1u : 0u;
@@ -468,7 +473,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             advance              = !retire & !leaf_done;
             pop                  = !retire & leaf_done;
         }
-        state = want_refs ? MRT_ST_REFS : ( ( advance & !is_test ) ? MRT_ST_TEST : state );
+        state = ( advance & !is_test ) ? MRT_ST_TEST : state;
         if ( pop ) {
             retire = sp == 0;
             if ( sp != 0 ) {
@@ -511,10 +516,6 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             want_node = true;
             node      = 0;
         }
-        if ( want_refs ) {
-            next  = ld_ref( s, ptr );
-            next2 = ptr + 1 < end ? ld_ref( s, ptr + 1 ) : 0u;
-        }
         if ( advance ) {
             // the record of the next primitive and the reference two ahead go in flight
             obj   = next;
@@ -526,9 +527,8 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             if ( ptr + 2 < end ) next2 = ld_ref( s, ptr + 2 );
         }
         if ( want_node ) {
-            const uint2 nd = ld_node( s, node );
-            L0.x           = __uint_as_float( nd.x );
-            L0.y           = __uint_as_float( nd.y );
+            const uint4 nd = ld_node( s, node );
+            L0             = make_float4( __uint_as_float( nd.x ), __uint_as_float( nd.y ), __uint_as_float( nd.z ), __uint_as_float( nd.w ) );
         }
     }
 }

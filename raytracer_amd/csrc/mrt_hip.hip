@@ -67,7 +67,7 @@ struct DevBuf {
 // ------------------------------------------------------------------------------------------------
 struct mrt_scene {
     int device = 0;
-    DevBuf<uint2> nodes;
+    DevBuf<uint4> nodes;
     DevBuf<uint32_t> refs;
     DevBuf<float4> prims;
     DevBuf<DXf> xforms;
@@ -162,7 +162,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     // the kernels address the scene tables with 32-bit byte offsets, and a hit record keeps the
     // object index in 31 bits
     if ( d->n_objects >= ( 1u << 26 ) || d->n_transforms >= ( 1u << 26 ) ) return fail( MRT_ERR_UNSUPPORTED, "too many objects or transforms (limit 2^26)" );
-    if ( d->n_nodes >= ( 1u << 29 ) || d->n_refs >= ( 1u << 30 ) ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree too large (limits: 2^29 nodes, 2^30 leaf references)" );
+    if ( d->n_nodes >= ( 1u << 28 ) || d->n_refs >= ( 1u << 30 ) ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree too large (limits: 2^28 nodes, 2^30 leaf references)" );
     {
         static const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
         static const float zero[3]  = { 0, 0, 0 };
@@ -221,9 +221,18 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         std::memcpy( xforms[i].m, d->transforms[i].m, 36 );
         xforms[i].pad[0] = xforms[i].pad[1] = xforms[i].pad[2] = 0.f;
     }
-    std::vector<uint2> nodes( d->n_nodes );
-    for ( uint32_t i = 0; i < d->n_nodes; i++ )
-        nodes[i] = make_uint2( d->nodes[i].w0, d->nodes[i].w1 );
+    // device node records are 16 bytes; a leaf carries its first two references (device_trace.hpp)
+    std::vector<uint4> nodes( d->n_nodes );
+    for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
+        const uint32_t w0 = d->nodes[i].w0, w1 = d->nodes[i].w1;
+        uint32_t r0 = 0, r1 = 0;
+        if ( ( w1 & 3u ) == 3u ) {
+            const uint32_t cnt = w1 >> 2;
+            if ( cnt > 0 ) r0 = d->refs[w0];
+            if ( cnt > 1 ) r1 = d->refs[w0 + 1];
+        }
+        nodes[i] = make_uint4( w0, w1, r0, r1 );
+    }
 
     std::unique_ptr<mrt_scene> s( new mrt_scene );
     s->device     = device;
