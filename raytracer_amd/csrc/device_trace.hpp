@@ -71,6 +71,7 @@ struct DTrace {
     uint32_t n_xforms;
     float root_min[3];
     float root_max[3];
+    uint32_t root[4]; // record of node 0: every ray starts from it without a load
 };
 
 struct DHit {
@@ -247,7 +248,6 @@ MRT_DEV bool clip_root( const DTrace& s, V3 o, V3 d, float& ray_tmin, float& ray
 #define MRT_ST_IDLE 0u  // no ray
 #define MRT_ST_INNER 1u // node record in flight
 #define MRT_ST_TEST 3u  // record of the current primitive in flight
-#define MRT_ST_FRESH 4u // fetched in this trip: the root node goes in flight at its end
 
 // Byte-offset loads: tables are addressed as base + 32-bit byte offset (checked at scene creation),
 // which the hardware forms from a scalar base and one vector register.
@@ -371,7 +371,8 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                         b     = ray_tmax;
                         sp    = 0;
                         has   = false;
-                        state = MRT_ST_FRESH;
+                        L0    = make_float4( __uint_as_float( s.root[0] ), __uint_as_float( s.root[1] ), __uint_as_float( s.root[2] ), __uint_as_float( s.root[3] ) );
+                        state = MRT_ST_INNER; // the root is stepped through in this very trip
                     }
                     else {
                         if ( STATS ) st.tests += pl_tests;
@@ -511,11 +512,6 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             state = MRT_ST_IDLE;
         }
         // ---------------------------------------------------------------- issue
-        if ( state == MRT_ST_FRESH ) {
-            state     = MRT_ST_INNER;
-            want_node = true;
-            node      = 0;
-        }
         if ( advance ) {
             // the record of the next primitive and the reference two ahead go in flight
             obj   = next;

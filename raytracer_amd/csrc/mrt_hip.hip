@@ -255,6 +255,9 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     t.n_nodes     = d->n_nodes;
     t.n_out       = d->n_out_of_tree;
     t.n_xforms    = d->n_transforms;
+    for ( int k = 0; k < 4; k++ )
+        t.root[k] = 0;
+    if ( !nodes.empty() ) t.root[0] = nodes[0].x, t.root[1] = nodes[0].y, t.root[2] = nodes[0].z, t.root[3] = nodes[0].w;
     for ( int k = 0; k < 3; k++ ) {
         t.root_min[k] = d->root_min[k];
         t.root_max[k] = d->root_max[k];
