@@ -30,7 +30,9 @@
 //
 // The deferred-node stack stores (node, tmax) only: the entry interval of a popped node is always
 // the exit value b of the leaf visited just before it (the same float, carried by assignment),
-// so it is not stored.
+// so it is not stored.  A deferred node is named by the record that holds it: bits 0-29 the
+// record, bit 31 set when it is one of the record's children (bit 30: the right one) rather than
+// the record's head.
 #pragma once
 #include "device_math.hpp"
 
@@ -49,10 +51,14 @@
 //   q2 = e2.yz  , material , 0      bit 3 emission.r+g+b != 0 (isBlack, integrator.cpp:110),
 //                                   bits 4.. transform index (0 = identity)
 //   e1 = p2 - p1, e2 = p3 - p1 (fp32, as triangle.cpp:9-10)
-// Device node record, 16 bytes.  An inner node uses the first 8 (split bits, axis | left << 2; its
-// children are adjacent, right = left + 1); a leaf is (first reference, 3 | count << 2, reference 0,
-// reference 1): its first two references arrive with the node itself, so no trip is spent waiting
-// for them.  Further references come from the reference list.
+// Device tree: 32-byte records, one per node of even depth (the root has depth 0), holding that
+// node and its two children, so one fetch serves two levels of the descent:
+//   q0 = head split bits, head axis (0..2; 3 = no head step, the left slot IS the node: a leaf of
+//        even depth), left child w0, left child w1
+//   q1 = right child w0, right child w1, first reference of the left child, of the right child
+// A child is an inner node (split bits, axis | record << 2: `record` holds its left child and
+// record + 1 its right child) or a leaf (first reference, 3 | count << 2); a leaf's first reference
+// arrives with the record, the further ones come from the reference list one trip ahead.
 #define MRT_PRIM_TRI 0u
 #define MRT_PRIM_SPHERE 1u
 #define MRT_PRIM_PLANE 2u
@@ -61,7 +67,7 @@
 #define MRT_PRIM_XF_SHIFT 4
 
 struct DTrace {
-    const uint4* nodes;
+    const uint4* nodes; // two uint4 per record
     const uint32_t* refs;
     const float4* prims;
     const DXf* xforms;
@@ -71,7 +77,7 @@ struct DTrace {
     uint32_t n_xforms;
     float root_min[3];
     float root_max[3];
-    uint32_t root[4]; // record of node 0: every ray starts from it without a load
+    uint32_t root[8]; // record 0: every ray starts from it without a load
 };
 
 struct DHit {
@@ -251,8 +257,8 @@ MRT_DEV bool clip_root( const DTrace& s, V3 o, V3 d, float& ray_tmin, float& ray
 
 // Byte-offset loads: tables are addressed as base + 32-bit byte offset (checked at scene creation),
 // which the hardware forms from a scalar base and one vector register.
-MRT_DEV uint4 ld_node( const DTrace& s, uint32_t node ) {
-    return *(const uint4*)( (const char*)s.nodes + ( node << 4 ) );
+MRT_DEV float4 ld_node( const DTrace& s, uint32_t rec, uint32_t half ) {
+    return *(const float4*)( (const char*)s.nodes + ( ( rec << 5 ) + half * 16u ) );
 }
 MRT_DEV uint32_t ld_ref( const DTrace& s, uint32_t i ) {
     return *(const uint32_t*)( (const char*)s.refs + ( i << 2 ) );
@@ -298,17 +304,26 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     uint32_t tag   = 0;
     V3 o = mk3( 0.f ), d = mk3( 0.f );
     float a = 0.f, b = 0.f, tmax = 0.f;
-    // Load registers: L0 is the node record in state INNER; L0, L1, L2 the primitive
+    // Load registers: L0, L1 are the tree record in state INNER; L0, L1, L2 the primitive
     // record in state TEST.
     float4 L0 = make_float4( 0.f, 0.f, 0.f, 0.f ), L1 = L0;
     float2 L2 = make_float2( 0.f, 0.f );
-    uint32_t ptr = 0, end = 0, obj = 0, next = 0, next2 = 0;
+    uint32_t ptr = 0, end = 0, obj = 0, next = 0;
+    uint32_t cur  = 0; // the record in L0, L1
+    uint32_t pick = 0; // after a pop: 2 = resume at the left child of the record, 3 = at the right one
     uint32_t xr_id = 0;    // transform of the object-space ray in LDS
     bool has       = false; // the current leaf has produced a hit (record in LDS, distance = tmax)
     bool has_pl    = false; // a plane was hit at fetch time (record in LDS)
     uint32_t pl_tests = 0;  // planes the reference would have tested for this ray (counters only)
     v2u stack_deep[MRT_STACK_MAX - MRT_STACK_LDS];
     int sp = 0;
+    auto push = [&]( uint32_t what, float upto ) {
+        v2u e;
+        e.x = what, e.y = __float_as_uint( upto );
+        if ( sp < MRT_STACK_LDS ) stack_lds[sp * MRT_TRACE_BLOCK] = e;
+        else stack_deep[sp - MRT_STACK_LDS] = e;
+        sp++;
+    };
 
     for ( ;; ) {
         // ---------------------------------------------------------------- refill
@@ -372,7 +387,10 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                         sp    = 0;
                         has   = false;
                         L0    = make_float4( __uint_as_float( s.root[0] ), __uint_as_float( s.root[1] ), __uint_as_float( s.root[2] ), __uint_as_float( s.root[3] ) );
-                        state = MRT_ST_INNER; // the root is stepped through in this very trip
+                        L1    = make_float4( __uint_as_float( s.root[4] ), __uint_as_float( s.root[5] ), __uint_as_float( s.root[6] ), __uint_as_float( s.root[7] ) );
+                        cur   = 0;
+                        pick  = 0;
+                        state = MRT_ST_INNER; // the root record is stepped through in this very trip
                     }
                     else {
                         if ( STATS ) st.tests += pl_tests;
@@ -398,12 +416,30 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         bool advance = false, retire = false, pop, want_node;
         uint32_t node;
         {
-            const uint32_t w0 = __float_as_uint( L0.x ), w1 = __float_as_uint( L0.y );
+            // first level: the head of the record picks one of the two children it holds (after
+            // a pop the child was picked when it was deferred)
+            const uint32_t h_axis = __float_as_uint( L0.y ) & 3u;
+            const bool forced     = ( pick != 0u ) | ( h_axis == 3u );
+            const bool at_head    = is_inner & !forced;
+            const float diff1     = L0.x - comp( o, h_axis );
+            const float t1        = diff1 / comp( d, h_axis );
+            const bool lnear1     = diff1 > 0.0f;
+            const bool near_only1 = ( t1 > b ) | ( t1 < 0.0f );
+            const bool far_only1  = !near_only1 & ( t1 < a );
+            const bool both1      = at_head & !near_only1 & !far_only1;
+            const bool right      = forced ? ( pick & 1u ) != 0u : ( lnear1 == far_only1 );
+            if ( both1 ) push( cur | ( lnear1 ? 0xc0000000u : 0x80000000u ), b ); // far = right iff near = left
+            b    = both1 ? t1 : b;
+            pick = 0u;
+            // second level: the child
+            const float w0f    = right ? L1.x : L0.z;
+            const uint32_t w0  = __float_as_uint( w0f );
+            const uint32_t w1  = __float_as_uint( right ? L1.y : L0.w );
+            const uint32_t r0  = __float_as_uint( right ? L1.w : L1.z );
             const bool at_node = is_inner & ( ( w1 & 3u ) != 3u ), at_leaf = is_inner & ( ( w1 & 3u ) == 3u );
-            // inner node
             const uint32_t axis = w1 & 3u;
             const uint32_t left = w1 >> 2;
-            const float diff    = L0.x - comp( o, axis );
+            const float diff    = w0f - comp( o, axis );
             const float t       = diff / comp( d, axis );
             const bool lnear    = diff > 0.0f;
             const uint32_t nr   = lnear ? left : left + 1;
@@ -413,13 +449,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             const bool both      = at_node & !near_only & !far_only;
             node                 = far_only ? fr : nr;
             want_node            = at_node;
-            if ( both ) {
-                v2u e;
-                e.x = fr, e.y = __float_as_uint( b );
-                if ( sp < MRT_STACK_LDS ) stack_lds[sp * MRT_TRACE_BLOCK] = e;
-                else stack_deep[sp - MRT_STACK_LDS] = e;
-            }
-            sp += both ? 1 : 0;
+            if ( both ) push( fr, b );
             // leaf: the ray interval becomes [a, b]
             tmax = at_leaf ? b : tmax;
             b    = both ? t : b;
@@ -428,10 +458,9 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             end  = at_leaf ? w0 + ( w1 >> 2 ) : end;
             pop       = at_leaf & ( ptr == end );
             advance   = at_leaf & ( ptr != end ); // the first record goes in flight in this trip
-            next      = at_leaf ? __float_as_uint( L0.z ) : next;
-            next2     = at_leaf ? __float_as_uint( L0.w ) : next2;
+            next      = at_leaf ? r0 : next;
             if ( STATS ) {
-                st.inner += at_node ? 1u : 0u;
+                st.inner += ( at_head ? 1u : 0u ) + ( at_node ? 1u : 0u );
                 st.leaves += at_leaf ? 1u : 0u;
             }
         }
@@ -484,7 +513,8 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 else e = stack_deep[sp - MRT_STACK_LDS];
                 a         = b;
                 b         = __uint_as_float( e.y );
-                node      = e.x;
+                node      = e.x & 0x3fffffffu;
+                pick      = e.x >> 30;
                 want_node = true;
                 state     = MRT_ST_INNER;
             }
@@ -513,18 +543,18 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         }
         // ---------------------------------------------------------------- issue
         if ( advance ) {
-            // the record of the next primitive and the reference two ahead go in flight
+            // the record of the next primitive and the reference after it go in flight
             obj   = next;
-            next  = next2;
             L0    = ld_prim( s, obj, 0 );
             L1    = ld_prim( s, obj, 1 );
             const float4 r2 = ld_prim( s, obj, 2 );
             L2    = make_float2( r2.x, r2.y );
-            if ( ptr + 2 < end ) next2 = ld_ref( s, ptr + 2 );
+            if ( ptr + 1 < end ) next = ld_ref( s, ptr + 1 );
         }
         if ( want_node ) {
-            const uint4 nd = ld_node( s, node );
-            L0             = make_float4( __uint_as_float( nd.x ), __uint_as_float( nd.y ), __uint_as_float( nd.z ), __uint_as_float( nd.w ) );
+            cur = node;
+            L0  = ld_node( s, node, 0 );
+            L1  = ld_node( s, node, 1 );
         }
     }
 }

@@ -221,17 +221,52 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         std::memcpy( xforms[i].m, d->transforms[i].m, 36 );
         xforms[i].pad[0] = xforms[i].pad[1] = xforms[i].pad[2] = 0.f;
     }
-    // device node records are 16 bytes; a leaf carries its first two references (device_trace.hpp)
-    std::vector<uint4> nodes( d->n_nodes );
-    for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
-        const uint32_t w0 = d->nodes[i].w0, w1 = d->nodes[i].w1;
-        uint32_t r0 = 0, r1 = 0;
-        if ( ( w1 & 3u ) == 3u ) {
-            const uint32_t cnt = w1 >> 2;
-            if ( cnt > 0 ) r0 = d->refs[w0];
-            if ( cnt > 1 ) r1 = d->refs[w0 + 1];
+    // device tree: one 32-byte record per node of even depth, holding the node and its two
+    // children (layout in device_trace.hpp); records follow the order of the caller's nodes
+    std::vector<uint4> nodes;
+    if ( d->n_nodes ) {
+        std::vector<uint8_t> level( d->n_nodes, 2 ); // depth parity, 2 = not reached
+        std::vector<uint32_t> todo( 1, 0u );
+        level[0] = 0;
+        while ( !todo.empty() ) {
+            const uint32_t n = todo.back();
+            todo.pop_back();
+            const uint32_t w1 = d->nodes[n].w1;
+            if ( ( w1 & 3u ) == 3u ) continue;
+            for ( uint32_t c = w1 >> 2; c <= ( w1 >> 2 ) + 1; c++ ) {
+                if ( level[c] != 2 ) return fail( MRT_ERR_INVALID, "a tree node has two parents" );
+                level[c] = level[n] ^ 1;
+                todo.push_back( c );
+            }
         }
-        nodes[i] = make_uint4( w0, w1, r0, r1 );
+        std::vector<uint32_t> record( d->n_nodes, 0 );
+        uint32_t n_records = 0;
+        for ( uint32_t i = 0; i < d->n_nodes; i++ )
+            if ( level[i] == 0 ) record[i] = n_records++;
+        // a child as the traversal reads it: (w0, w1, first reference)
+        auto child = [&]( uint32_t n, uint32_t out[3] ) {
+            const uint32_t w0 = d->nodes[n].w0, w1 = d->nodes[n].w1;
+            out[0] = w0, out[1] = w1, out[2] = 0;
+            if ( ( w1 & 3u ) == 3u ) {
+                if ( ( w1 >> 2 ) > 0 ) out[2] = d->refs[w0];
+            }
+            else out[1] = ( w1 & 3u ) | ( record[w1 >> 2] << 2 ); // its children are adjacent nodes of even depth: adjacent records
+        };
+        nodes.assign( 2 * (size_t)n_records, make_uint4( 0, 0, 0, 0 ) );
+        for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
+            if ( level[i] != 0 ) continue;
+            const uint32_t w0 = d->nodes[i].w0, w1 = d->nodes[i].w1;
+            uint32_t l[3] = { 0, 0, 0 }, r[3] = { 0, 0, 0 };
+            uint32_t h0 = 0, h1 = 3;
+            if ( ( w1 & 3u ) == 3u ) child( i, l ); // a leaf of even depth: no head step
+            else {
+                h0 = w0, h1 = w1 & 3u;
+                child( w1 >> 2, l );
+                child( ( w1 >> 2 ) + 1, r );
+            }
+            nodes[2 * (size_t)record[i]]     = make_uint4( h0, h1, l[0], l[1] );
+            nodes[2 * (size_t)record[i] + 1] = make_uint4( r[0], r[1], l[2], r[2] );
+        }
     }
 
     std::unique_ptr<mrt_scene> s( new mrt_scene );
@@ -255,9 +290,12 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     t.n_nodes     = d->n_nodes;
     t.n_out       = d->n_out_of_tree;
     t.n_xforms    = d->n_transforms;
-    for ( int k = 0; k < 4; k++ )
+    for ( int k = 0; k < 8; k++ )
         t.root[k] = 0;
-    if ( !nodes.empty() ) t.root[0] = nodes[0].x, t.root[1] = nodes[0].y, t.root[2] = nodes[0].z, t.root[3] = nodes[0].w;
+    if ( !nodes.empty() ) {
+        const uint32_t r[8] = { nodes[0].x, nodes[0].y, nodes[0].z, nodes[0].w, nodes[1].x, nodes[1].y, nodes[1].z, nodes[1].w };
+        std::memcpy( t.root, r, sizeof( r ) );
+    }
     for ( int k = 0; k < 3; k++ ) {
         t.root_min[k] = d->root_min[k];
         t.root_max[k] = d->root_max[k];
