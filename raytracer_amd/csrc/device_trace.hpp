@@ -20,12 +20,13 @@
 //     here the planes are tested when a ray is fetched (nearest plane, first one on ties; for
 //     any-hit rays the first accepted plane) and merged with the tree result when the ray retires.
 //
-// Execution model: streaming traversal.  A wave owns an interleaved share of the ray list and every
+// Execution model: streaming traversal.  The waves draw 64-ray chunks of the ray list from
+// counters (one per eighth of the list, see trace_stream) and every
 // lane is a small state machine (idle / node / primitive test).  One trip of
 // the wave's loop performs, for every lane, the work that depends on the loads issued in the trip
 // before and issues the next loads, so a trip costs one memory round trip however the lanes'
-// states are mixed; lanes whose ray retired are refilled from the wave's share once enough of
-// them are idle.  Rays differ in length by orders of magnitude, so without the refill a wave runs
+// states are mixed; lanes whose ray retired are refilled from the wave's current chunk once enough
+// of them are idle.  Rays differ in length by orders of magnitude, so without the refill a wave runs
 // at the pace of its longest ray with most lanes idle.
 //
 // The deferred-node stack stores (node, tmax) only: the entry interval of a popped node is always
@@ -274,8 +275,18 @@ MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
 // a plane retires without entering the tree.  Every thread of the grid must call this (it uses
 // wave-wide votes and a block barrier); blockDim.x must be MRT_TRACE_BLOCK; `lds` must hold
 // MRT_TRACE_LDS_WORDS 32-bit words.
+//
+// Dealing: the list is cut into eight contiguous parts, one per XCD (workgroups go to the XCDs
+// round-robin, so blockIdx.x & 7 names the XCD), each with a counter in `deal` (eight counters
+// MRT_DEAL_STRIDE words apart, zero at launch).  A wave draws the next 64-ray chunk of its XCD's
+// part, and of the following parts once that one is exhausted.  The rays in flight on one XCD are
+// therefore consecutive in the list - for path tracing: neighbouring pixels - and share the tree
+// nodes and primitives they pull through that XCD's L2; and no wave is left with a longer share
+// than the others.
+#define MRT_DEAL_STRIDE 32u
+#define MRT_DEAL_WORDS ( 8u * MRT_DEAL_STRIDE )
 template <bool ANY, bool BOOL_ONLY, bool STATS, class IO>
-MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t n, DStats& st ) {
+MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t n, uint32_t* deal, DStats& st ) {
     const lds_f32* xf_lds = (const lds_f32*)( lds + MRT_LDS_XF );
     stage_transforms( s, (lds_f32*)( lds + MRT_LDS_XF ) );
     lds_u2* stack_lds = (lds_u2*)( lds + MRT_LDS_STACK ) + threadIdx.x;
@@ -293,12 +304,11 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     };
     lds_f4* pl_lds    = (lds_f4*)( lds + MRT_LDS_PL ) + threadIdx.x;
 
-    // Ray list shares: 64-ray chunks dealt round-robin to the waves of the grid; `taken` counts
-    // the rays this wave has fetched from its share.
     const uint32_t n_chunks = ( n + 63u ) >> 6;
-    const uint32_t wave     = ( blockIdx.x * blockDim.x + threadIdx.x ) >> 6;
-    const uint32_t n_waves  = ( gridDim.x * blockDim.x ) >> 6;
-    uint32_t taken = 0;
+    const uint32_t per_part = ( n_chunks + 7u ) >> 3;
+    uint32_t part_try = 0;          // parts found exhausted so far, counted from this XCD's own
+    uint32_t chunk = 0, left = 0;   // first ray of the wave's current chunk, rays not yet taken from it
+    bool more      = n_chunks != 0; // some part may still have chunks
 
     uint32_t state = MRT_ST_IDLE;
     uint32_t tag   = 0;
@@ -329,14 +339,23 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         // ---------------------------------------------------------------- refill
         const unsigned long long idle = __ballot( state == MRT_ST_IDLE );
         const uint32_t n_idle         = (uint32_t)__popcll( idle );
-        const bool more               = ( taken >> 6 ) * n_waves + wave < n_chunks;
         if ( !more && n_idle == 64u ) break;
         if ( more && n_idle >= MRT_REFILL_MIN ) {
+            while ( left == 0 && part_try < 8u ) {
+                const uint32_t part = ( ( blockIdx.x & 7u ) + part_try ) & 7u;
+                uint32_t got        = 0;
+                if ( __lane_id() == 0 ) got = atomicAdd( deal + part * MRT_DEAL_STRIDE, 1u );
+                got                 = (uint32_t)__builtin_amdgcn_readfirstlane( (int)got );
+                const uint32_t c    = part * per_part + got;
+                if ( got < per_part && c < n_chunks ) chunk = c << 6, left = 64u;
+                else part_try++;
+            }
+            more = left != 0;
+            const uint32_t take = n_idle < left ? n_idle : left;
             if ( state == MRT_ST_IDLE ) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( idle >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)idle, 0u ) );
-                const uint32_t j    = taken + rank;
-                const uint32_t idx  = ( ( j >> 6 ) * n_waves + wave ) * 64u + ( j & 63u );
-                if ( idx < n ) {
+                const uint32_t idx  = chunk + ( 64u - left ) + rank;
+                if ( rank < take && idx < n ) {
                     float ray_tmin, ray_tmax;
                     io.load( idx, tag, o, d, ray_tmin, ray_tmax );
                     xr_id    = 0;
@@ -404,7 +423,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                     }
                 }
             }
-            taken += n_idle;
+            left -= take;
         }
 
         // ---------------------------------------------------------------- one step per lane

@@ -85,7 +85,7 @@ struct mrt_scene {
     DTrace trace {};
     DShade shade {};
     RenderWorkspace ws;
-    uint64_t* d_stats = nullptr; // 8 x u64 scratch for counters
+    uint64_t* d_stats = nullptr; // mrt_intersect: 8 x u64 traversal counters, then the MRT_DEAL_WORDS chunk counters
     uint32_t tree_depth = 0;
     int n_cus           = 256;
     bool no_emitters    = false; // no object has a material with a non-zero emission component
@@ -279,7 +279,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     HIP_TRY( s->prims.upload( prims ) );
     HIP_TRY( s->xforms.upload( xforms ) );
     HIP_TRY( s->out_of_tree.upload( std::vector<uint32_t>( d->out_of_tree, d->out_of_tree + d->n_out_of_tree ) ) );
-    HIP_TRY( hipMalloc( (void**)&s->d_stats, 8 * sizeof( uint64_t ) ) );
+    HIP_TRY( hipMalloc( (void**)&s->d_stats, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ) ) );
 
     DTrace& t     = s->trace;
     t.nodes       = s->nodes.p;
@@ -338,11 +338,11 @@ struct BatchIO {
 };
 
 template <bool ANY, bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) trace_batch_kernel( DTrace s, BatchIO io, uint32_t n, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) trace_batch_kernel( DTrace s, BatchIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
-    trace_stream<ANY, false, STATS>( s, lp, io, n, st );
+    trace_stream<ANY, false, STATS>( s, lp, io, n, deal, st );
     if ( STATS ) flush_stats( st, stats );
 }
 
@@ -395,12 +395,12 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
         du    = hits->u;
         dv    = hits->v;
     }
-    if ( stats ) HIP_TRY( hipMemsetAsync( sc->d_stats, 0, 8 * sizeof( uint64_t ), stream ) );
+    HIP_TRY( hipMemsetAsync( sc->d_stats, 0, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ), stream ) );
     const dim3 block( MRT_TRACE_BLOCK );
     unsigned long long* ds = (unsigned long long*)sc->d_stats;
     const BatchIO io { din[0], din[1], din[2], din[3], din[4], din[5], din[6], din[7], dprim, dt, du, dv };
 #define LAUNCH( A, S ) \
-    hipLaunchKernelGGL( ( trace_batch_kernel<A, S> ), dim3( trace_grid_blocks( trace_batch_kernel<A, S>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, ds )
+    hipLaunchKernelGGL( ( trace_batch_kernel<A, S> ), dim3( trace_grid_blocks( trace_batch_kernel<A, S>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, (uint32_t*)( sc->d_stats + 8 ), ds )
     if ( flags == MRT_ANY_HIT ) {
         if ( stats ) LAUNCH( true, true );
         else LAUNCH( true, false );
