@@ -84,23 +84,49 @@ struct PassInfo {
     uint32_t max_depth;
 };
 
+// A pass made of whole 8x8 pixel tiles numbers its pixels and paths tile by tile.
+MRT_DEV bool pass_tiled( const PassInfo& pi ) {
+#ifndef MRT_NO_TILES
+    return ( ( pi.width | pi.n_rows ) & 7u ) == 0u;
+#else
+    return false;
+#endif
+}
+
 // Pixel of the pass that path-local index p_local stands for.  When the pass is made of whole 8x8
 // tiles the pixels are numbered tile by tile, so that 64 consecutive paths (a wave's first rays, a
 // queue's neighbours) cover a square of the image instead of a 64-pixel line: their rays start
 // closer together and walk more of the same subtrees.  Otherwise scanline order.
 MRT_DEV void pass_pixel( const PassInfo& pi, uint32_t p_local, uint32_t& x, uint32_t& y ) {
-#ifndef MRT_NO_TILES
-    if ( ( ( pi.width | pi.n_rows ) & 7u ) == 0u ) {
+    if ( pass_tiled( pi ) ) {
         const uint32_t tile = p_local >> 6, in = p_local & 63u, tiles_x = pi.width >> 3;
         const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
         x = ( tx << 3 ) + ( in & 7u );
         y = pi.row_begin + ( ty << 3 ) + ( in >> 3 );
         return;
     }
-#endif
     const uint32_t r = p_local / pi.width;
     x = p_local - r * pi.width;
     y = pi.row_begin + r;
+}
+
+// Path id of sample s_local of pixel p_local, and back.  In a tiled pass the samples of one tile
+// are numbered together: (tile, sample, pixel in tile), so consecutive 64-path chunks are the
+// same 64 pixels at consecutive sample indices and the rays in flight at any time come from a few
+// tiles of the image.  Otherwise (sample, pixel).
+MRT_DEV uint32_t pass_path( const PassInfo& pi, uint32_t s_local, uint32_t p_local ) {
+    if ( pass_tiled( pi ) ) return ( ( ( p_local >> 6 ) * pi.n_samples + s_local ) << 6 ) | ( p_local & 63u );
+    return s_local * pi.n_pixels + p_local;
+}
+MRT_DEV void pass_split( const PassInfo& pi, uint32_t id, uint32_t& s_local, uint32_t& p_local ) {
+    if ( pass_tiled( pi ) ) {
+        const uint32_t chunk = id >> 6, tile = chunk / pi.n_samples;
+        s_local = chunk - tile * pi.n_samples;
+        p_local = ( tile << 6 ) | ( id & 63u );
+        return;
+    }
+    s_local = id / pi.n_pixels;
+    p_local = id - s_local * pi.n_pixels;
 }
 
 struct Queues {
@@ -155,7 +181,8 @@ MRT_DEV void queue_push3( uint32_t* const* queue, uint32_t* counters, const bool
 __global__ void __launch_bounds__( 256 ) generate_kernel( PathState ps, PassInfo pi, DCamera cam ) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if ( id >= pi.n_paths ) return;
-    const uint32_t s_local = id / pi.n_pixels, p_local = id - s_local * pi.n_pixels;
+    uint32_t s_local, p_local;
+    pass_split( pi, id, s_local, p_local );
     uint32_t x, y;
     pass_pixel( pi, p_local, x, y );
     const uint32_t pixel  = y * pi.width + x;
@@ -234,7 +261,8 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
             Pcg32 rng;
             rng.state = ps.rng_state[id];
             rng.inc   = ps.rng_inc[id];
-            const uint32_t s_local = id / pi.n_pixels, p_local = id - s_local * pi.n_pixels;
+            uint32_t s_local, p_local;
+            pass_split( pi, id, s_local, p_local );
             uint32_t px, py;
             pass_pixel( pi, p_local, px, py );
             const uint32_t pixel = py * pi.width + px;
@@ -459,7 +487,7 @@ __global__ void __launch_bounds__( 256 ) accumulate_kernel( PathState ps, PassIn
     if ( p >= pi.n_pixels ) return;
     V3 sum = mk3( 0.f );
     for ( uint32_t s = 0; s < pi.n_samples; s++ ) {
-        const uint32_t id = s * pi.n_pixels + p;
+        const uint32_t id = pass_path( pi, s, p );
         V3 L              = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
         fold_pending( ps, id, L );
         sum = sum + L;
