@@ -460,7 +460,7 @@ __global__ void __launch_bounds__( 256 ) mis_resolve_kernel( DTrace tr, DShade s
         const uint32_t li = ps.mlight[id];
         V3 Li             = mk3( 0.f );
         if ( h.prim >= 0 ) { // integrator.cpp:108-113
-            const uint32_t flags = __float_as_uint( tr.prims[3 * (size_t)h.prim].w );
+            const uint32_t flags = __float_as_uint( tr.prims[MRT_PRIM_Q * (size_t)h.prim].w );
             if ( flags & MRT_PRIM_EMISSIVE_SUM ) {
                 Surf sf = surface_from_hit( tr, sh, o, d, h );
                 // `wi` of the reference is the un-normalised sample direction; the ray direction is

@@ -43,10 +43,10 @@
 #define MRT_XF_LDS 64 // transforms kept in LDS (12 floats each); the rest are read from HBM
 #endif
 #ifndef MRT_REFILL_MIN
-#define MRT_REFILL_MIN 8 // idle lanes that trigger a refill of the wave
+#define MRT_REFILL_MIN 16 // idle lanes that trigger a refill of the wave
 #endif
 
-// prim record: 3 x float4
+// prim record: 3 x float4 in a 64-byte slot (a record never straddles two cache lines)
 //   q0 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane),
 //   q1 = e1.xyz , e2.x              bit 2 emission != (0,0,0) component-wise (kdtree.cpp:533-534),
 //   q2 = e2.yz  , material , 0      bit 3 emission.r+g+b != 0 (isBlack, integrator.cpp:110),
@@ -60,6 +60,9 @@
 // A child is an inner node (split bits, axis | record << 2: `record` holds its left child and
 // record + 1 its right child) or a leaf (first reference, 3 | count << 2); a leaf's first reference
 // arrives with the record, the further ones come from the reference list one trip ahead.
+#ifndef MRT_PRIM_Q
+#define MRT_PRIM_Q 4 // float4 per primitive record: three used, padded to one 64-byte line
+#endif
 #define MRT_PRIM_TRI 0u
 #define MRT_PRIM_SPHERE 1u
 #define MRT_PRIM_PLANE 2u
@@ -265,7 +268,7 @@ MRT_DEV uint32_t ld_ref( const DTrace& s, uint32_t i ) {
     return *(const uint32_t*)( (const char*)s.refs + ( i << 2 ) );
 }
 MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
-    return *(const float4*)( (const char*)s.prims + ( obj * 48u + k * 16u ) );
+    return *(const float4*)( (const char*)s.prims + ( obj * ( MRT_PRIM_Q * 16u ) + k * 16u ) );
 }
 
 // Traces rays 0..n-1 of `io` with the whole grid.

@@ -187,7 +187,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     HIP_TRY( hipDeviceGetAttribute( &n_cus, hipDeviceAttributeMultiprocessorCount, device ) );
 
     bool no_emitters = true;
-    std::vector<float4> prims( 3 * (size_t)d->n_objects );
+    std::vector<float4> prims( MRT_PRIM_Q * (size_t)d->n_objects, make_float4( 0.f, 0.f, 0.f, 0.f ) );
     for ( uint32_t i = 0; i < d->n_objects; i++ ) {
         uint32_t kind = d->obj_kind[i], mat = d->obj_material[i], xf = d->obj_transform[i];
         if ( mat >= d->n_materials ) return fail( MRT_ERR_INVALID, "object material out of range" );
@@ -210,9 +210,9 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         // e1 = p2 - p1, e2 = p3 - p1: one fp32 subtraction each, as triangle.cpp:9-10 does per test
         float e1[3] = { p[3] - p[0], p[4] - p[1], p[5] - p[2] };
         float e2[3] = { p[6] - p[0], p[7] - p[1], p[8] - p[2] };
-        prims[3 * (size_t)i]     = make_float4( p[0], p[1], p[2], fl );
-        prims[3 * (size_t)i + 1] = make_float4( e1[0], e1[1], e1[2], e2[0] );
-        prims[3 * (size_t)i + 2] = make_float4( e2[1], e2[2], fm, 0.f );
+        prims[MRT_PRIM_Q * (size_t)i]     = make_float4( p[0], p[1], p[2], fl );
+        prims[MRT_PRIM_Q * (size_t)i + 1] = make_float4( e1[0], e1[1], e1[2], e2[0] );
+        prims[MRT_PRIM_Q * (size_t)i + 2] = make_float4( e2[1], e2[2], fm, 0.f );
     }
     std::vector<DXf> xforms( d->n_transforms );
     for ( uint32_t i = 0; i < d->n_transforms; i++ ) {
