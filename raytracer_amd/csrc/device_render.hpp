@@ -85,6 +85,7 @@ struct PassInfo {
 };
 
 // A pass made of whole 8x8 pixel tiles numbers its pixels and paths tile by tile.
+#define MRT_TILE_STRIPS 4u
 MRT_DEV bool pass_tiled( const PassInfo& pi ) {
 #ifndef MRT_NO_TILES
     return ( ( pi.width | pi.n_rows ) & 7u ) == 0u;
@@ -100,7 +101,15 @@ MRT_DEV bool pass_tiled( const PassInfo& pi ) {
 MRT_DEV void pass_pixel( const PassInfo& pi, uint32_t p_local, uint32_t& x, uint32_t& y ) {
     if ( pass_tiled( pi ) ) {
         const uint32_t tile = p_local >> 6, in = p_local & 63u, tiles_x = pi.width >> 3;
-        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        if ( ( tiles_x & ( MRT_TILE_STRIPS - 1u ) ) == 0u ) {
+            // tiles run down vertical strips MRT_TILE_STRIPS tiles wide: a tile's successors are
+            // its neighbours in both directions, not only along the scanline
+            const uint32_t tiles_y = pi.n_rows >> 3, per_strip = tiles_y * MRT_TILE_STRIPS;
+            const uint32_t strip = tile / per_strip, r = tile - strip * per_strip;
+            ty = r / MRT_TILE_STRIPS;
+            tx = strip * MRT_TILE_STRIPS + ( r - ty * MRT_TILE_STRIPS );
+        }
         x = ( tx << 3 ) + ( in & 7u );
         y = pi.row_begin + ( ty << 3 ) + ( in >> 3 );
         return;
