@@ -131,6 +131,58 @@ mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out ) {
     return MRT_OK;
 }
 
+// The tree as the kernels read it: one 32-byte record (two uint4) per node of even depth, holding
+// the node and its two children (layout in device_trace.hpp); records follow the order of the
+// caller's nodes.  Expects a tree that passed validate_tree.
+mrt_status build_tree_records( const mrt_scene_desc* d, std::vector<uint4>& nodes ) {
+    nodes.clear();
+    if ( d->n_nodes ) {
+        std::vector<uint8_t> level( d->n_nodes, 2 ); // depth parity, 2 = not reached
+        std::vector<uint32_t> todo( 1, 0u );
+        level[0] = 0;
+        while ( !todo.empty() ) {
+            const uint32_t n = todo.back();
+            todo.pop_back();
+            const uint32_t w1 = d->nodes[n].w1;
+            if ( ( w1 & 3u ) == 3u ) continue;
+            for ( uint32_t c = w1 >> 2; c <= ( w1 >> 2 ) + 1; c++ ) {
+                if ( level[c] != 2 ) return fail( MRT_ERR_INVALID, "a tree node has two parents" );
+                level[c] = level[n] ^ 1;
+                todo.push_back( c );
+            }
+        }
+        std::vector<uint32_t> record( d->n_nodes, 0 );
+        uint32_t n_records = 0;
+        for ( uint32_t i = 0; i < d->n_nodes; i++ )
+            if ( level[i] == 0 ) record[i] = n_records++;
+        // a child as the traversal reads it: (w0, w1, first reference)
+        auto child = [&]( uint32_t n, uint32_t out[3] ) {
+            const uint32_t w0 = d->nodes[n].w0, w1 = d->nodes[n].w1;
+            out[0] = w0, out[1] = w1, out[2] = 0;
+            if ( ( w1 & 3u ) == 3u ) {
+                if ( ( w1 >> 2 ) > 0 ) out[2] = d->refs[w0];
+            }
+            else out[1] = ( w1 & 3u ) | ( record[w1 >> 2] << 2 ); // its children are adjacent nodes of even depth: adjacent records
+        };
+        nodes.assign( 2 * (size_t)n_records, make_uint4( 0, 0, 0, 0 ) );
+        for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
+            if ( level[i] != 0 ) continue;
+            const uint32_t w0 = d->nodes[i].w0, w1 = d->nodes[i].w1;
+            uint32_t l[3] = { 0, 0, 0 }, r[3] = { 0, 0, 0 };
+            uint32_t h0 = 0, h1 = 3;
+            if ( ( w1 & 3u ) == 3u ) child( i, l ); // a leaf of even depth: no head step
+            else {
+                h0 = w0, h1 = w1 & 3u;
+                child( w1 >> 2, l );
+                child( ( w1 >> 2 ) + 1, r );
+            }
+            nodes[2 * (size_t)record[i]]     = make_uint4( h0, h1, l[0], l[1] );
+            nodes[2 * (size_t)record[i] + 1] = make_uint4( r[0], r[1], l[2], r[2] );
+        }
+    }
+    return MRT_OK;
+}
+
 } // namespace
 
 static mrt_status upload_shading( const mrt_scene_desc* d, mrt_scene* s ); // render_host.inc
@@ -172,6 +224,9 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     }
     uint32_t depth = 0;
     mrt_status vs  = validate_tree( d, &depth );
+    if ( vs != MRT_OK ) return vs;
+    std::vector<uint4> nodes;
+    vs = build_tree_records( d, nodes );
     if ( vs != MRT_OK ) return vs;
     for ( uint32_t i = 0; i < d->n_out_of_tree; i++ ) {
         if ( d->out_of_tree[i] >= d->n_objects ) return fail( MRT_ERR_INVALID, "out_of_tree index out of range" );
@@ -221,54 +276,6 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         std::memcpy( xforms[i].m, d->transforms[i].m, 36 );
         xforms[i].pad[0] = xforms[i].pad[1] = xforms[i].pad[2] = 0.f;
     }
-    // device tree: one 32-byte record per node of even depth, holding the node and its two
-    // children (layout in device_trace.hpp); records follow the order of the caller's nodes
-    std::vector<uint4> nodes;
-    if ( d->n_nodes ) {
-        std::vector<uint8_t> level( d->n_nodes, 2 ); // depth parity, 2 = not reached
-        std::vector<uint32_t> todo( 1, 0u );
-        level[0] = 0;
-        while ( !todo.empty() ) {
-            const uint32_t n = todo.back();
-            todo.pop_back();
-            const uint32_t w1 = d->nodes[n].w1;
-            if ( ( w1 & 3u ) == 3u ) continue;
-            for ( uint32_t c = w1 >> 2; c <= ( w1 >> 2 ) + 1; c++ ) {
-                if ( level[c] != 2 ) return fail( MRT_ERR_INVALID, "a tree node has two parents" );
-                level[c] = level[n] ^ 1;
-                todo.push_back( c );
-            }
-        }
-        std::vector<uint32_t> record( d->n_nodes, 0 );
-        uint32_t n_records = 0;
-        for ( uint32_t i = 0; i < d->n_nodes; i++ )
-            if ( level[i] == 0 ) record[i] = n_records++;
-        // a child as the traversal reads it: (w0, w1, first reference)
-        auto child = [&]( uint32_t n, uint32_t out[3] ) {
-            const uint32_t w0 = d->nodes[n].w0, w1 = d->nodes[n].w1;
-            out[0] = w0, out[1] = w1, out[2] = 0;
-            if ( ( w1 & 3u ) == 3u ) {
-                if ( ( w1 >> 2 ) > 0 ) out[2] = d->refs[w0];
-            }
-            else out[1] = ( w1 & 3u ) | ( record[w1 >> 2] << 2 ); // its children are adjacent nodes of even depth: adjacent records
-        };
-        nodes.assign( 2 * (size_t)n_records, make_uint4( 0, 0, 0, 0 ) );
-        for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
-            if ( level[i] != 0 ) continue;
-            const uint32_t w0 = d->nodes[i].w0, w1 = d->nodes[i].w1;
-            uint32_t l[3] = { 0, 0, 0 }, r[3] = { 0, 0, 0 };
-            uint32_t h0 = 0, h1 = 3;
-            if ( ( w1 & 3u ) == 3u ) child( i, l ); // a leaf of even depth: no head step
-            else {
-                h0 = w0, h1 = w1 & 3u;
-                child( w1 >> 2, l );
-                child( ( w1 >> 2 ) + 1, r );
-            }
-            nodes[2 * (size_t)record[i]]     = make_uint4( h0, h1, l[0], l[1] );
-            nodes[2 * (size_t)record[i] + 1] = make_uint4( r[0], r[1], l[2], r[2] );
-        }
-    }
-
     std::unique_ptr<mrt_scene> s( new mrt_scene );
     s->device     = device;
     s->tree_depth = depth;

@@ -226,6 +226,23 @@ def test_scene_create_rejects_malformed_descriptions(built):
     st, msg, _ = try_create(sphere_out_of_tree)
     assert st == 1 and "planes only" in msg
 
+    def shared_child(d):
+        # an inner node whose children are its parent's children: every index is in range and the
+        # children follow their parent, but the tree is not a tree
+        nodes = (abi.KdNode * d.n_nodes)()
+        C.memmove(nodes, d.nodes, C.sizeof(nodes))
+        root_left = nodes[0].w1 >> 2
+        inner = next(i for i in range(1, d.n_nodes) if (nodes[i].w1 & 3) != 3 and (nodes[i].w1 >> 2) > root_left + 1)
+        other = next(i for i in range(inner + 1, d.n_nodes) if (nodes[i].w1 & 3) != 3)
+        nodes[other].w1 = (nodes[other].w1 & 3) | ((nodes[inner].w1 >> 2) << 2)
+        if (nodes[other].w1 >> 2) <= other:
+            return None
+        d.nodes = nodes
+        return nodes
+    st, msg, keep = try_create(shared_child)
+    if keep is not None:
+        assert st == 1 and ("two parents" in msg or "visits more nodes" in msg), (st, msg)
+
     def too_many_nodes(d):
         d.n_nodes = 1 << 29
     st, msg, _ = try_create(too_many_nodes)
