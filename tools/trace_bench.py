@@ -54,16 +54,27 @@ def main():
     hit = prim >= 0
     g = torch.Generator(device="cuda")
     g.manual_seed(7)
-    sos, sds = [], []
+    sos, sds, ws = [], [], []
     for _ in range(a.mult):  # one "sample" after another, pixels in scanline order within each
         w = torch.randn((n, 3), device="cuda", generator=g)
         w = w / w.norm(dim=1, keepdim=True)
         flip = (w * td).sum(1) > 0
         w[flip] = -w[flip]
+        ws.append(w)
         sos.append((to + t[:, None] * td + 1e-3 * w)[hit])
         sds.append(w[hit])
-    so = torch.cat(sos).contiguous()
-    sd = torch.cat(sds).contiguous()
+    if a.tile:
+        # the renderer's order: (tile, sample, pixel in tile)
+        def tile_major(parts):
+            x = torch.stack(parts).reshape(a.mult, n // 64, 64, -1).permute(1, 0, 2, 3).reshape(a.mult * n, -1)
+            return x
+        keep = tile_major([hit[:, None].float()] * a.mult)[:, 0] > 0
+        allo = tile_major([to + t[:, None] * td + 1e-3 * w_ for w_ in ws])
+        alld = tile_major(ws)
+        so, sd = allo[keep].contiguous(), alld[keep].contiguous()
+    else:
+        so = torch.cat(sos).contiguous()
+        sd = torch.cat(sds).contiguous()
     if a.octant:
         # within every run of a.octant consecutive rays, group the rays by the signs of their direction
         m = len(so)
