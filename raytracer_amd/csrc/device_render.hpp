@@ -3,10 +3,9 @@
 // It computes what CPURenderer::run does for one camera sample (rendering/CPURenderer.cpp:46-62):
 // camera sample, SimpleCamera::get_ray, then Pathtracer::trace_ray (integrator.cpp:128-211) with
 // directIllumination (integrator.cpp:69-120).  One path = one camera sample; all per-path state is
-// struct-of-arrays in HBM, indexed by the path id
-//     id = sample_local * n_pixels + pixel_local
-// so that the 64 lanes of a wave hold 64 neighbouring pixels of one sample index (coherent
-// primary rays, coalesced state access).  Work lists are queues of path ids; the kernels are
+// struct-of-arrays in HBM, indexed by the path id (pass_path below: tile, sample, pixel in tile),
+// so that the 64 lanes of a wave hold an 8x8 pixel tile at one sample index (coherent primary
+// rays, coalesced state access) and consecutive 64-path chunks the same tile at the next samples.  Work lists are queues of path ids; the kernels are
 //   generate        camera sample + primary ray for every id
 //   extend          closest-hit traversal of the continuation ray of every live path
 //   shade           everything of one loop iteration of trace_ray that needs no further ray:
