@@ -169,6 +169,18 @@ int mrth_material_set_image( void* scene_, int id, uint32_t w, uint32_t h, const
     scene->GetMaterial( id ).m_texture = t;
     return 0;
 }
+int mrth_materials_share_texture( void* scene_, int from_id, int first_id, int last_id ) {
+    auto* scene = static_cast<Scene*>( scene_ );
+    const int n = (int)scene->m_Materials.size();
+    if ( from_id < 0 || from_id >= n || first_id < 0 || last_id >= n || first_id > last_id ) {
+        g_err = "material id out of range";
+        return -1;
+    }
+    texture* t = scene->GetMaterial( from_id ).m_texture;
+    for ( int id = first_id; id <= last_id; id++ )
+        scene->GetMaterial( id ).m_texture = t;
+    return 0;
+}
 int mrth_n_objects( void* scene ) {
     return (int)static_cast<Scene*>( scene )->objects.size();
 }

@@ -95,6 +95,11 @@ class Scene:
         h, w, _ = rgb.shape
         abi.host().mrth_material_set_image(self._h, mat, w, h, _fp(rgb.reshape(-1)), tex_xf._h if tex_xf else None)
 
+    def share_texture(self, from_mat, first, last):
+        """Materials first..last use the texture of from_mat (the texels are stored once)."""
+        if abi.host().mrth_materials_share_texture(self._h, from_mat, first, last) != 0:
+            raise MrtError(abi.host().mrth_last_error().decode())
+
     def material(self, mid):
         m = abi.Material()
         if abi.host().mrth_material_get(self._h, mid, C.byref(m)) != 0:

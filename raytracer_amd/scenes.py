@@ -6,6 +6,7 @@ example scenes assemble theirs (example_scenes.cpp), with repository-local asset
                (example_scenes.cpp:1371-1459; the reference's 4k map is not distributed, the 1k one is)
   veach_mi     scene 21: four sphere emitters, four rough plates, floor (example_scenes.cpp:1461-1592)
   stress       the bunny mesh 1->4 subdivided `subdivisions` times: the ~1M-triangle kd-tree stress case
+  plant        indoor_plant_02.obj + MTL (one material per triangle) with its colour map, HDR env
 """
 import os
 
@@ -92,6 +93,55 @@ def million_bunny(width=1920, height=1080, env="brown_photostudio_06_1k.hdr"):
     sc.add_plane(Transform().scale(32, 32, 1).rotate((-1, 0, 0), 90).translate((0, 2.64, 0)), floor)
     body = sc.CreateMaterial(abi.MRT_MAT_SPECULAR, albedo=(1, 1, 1), roughness=0.2, metalness=0.9)
     sc.addObjectsFromFile(asset("stanford-bunny.obj"), body, Transform(), prescale=80.0, subdivisions=2)
+    return sc
+
+
+def read_ppm(path):
+    """Binary PPM (P6, 8 bit) as float32 [h][w][3] in 0..1: the values image_texture keeps
+    (8-bit channel / 255, textures.hpp:64-76)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    fields, pos = [], 0
+    while len(fields) < 4:
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b"#":
+            pos = data.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not data[end:end + 1].isspace():
+            end += 1
+        fields.append(data[pos:end])
+        pos = end
+    if fields[0] != b"P6" or int(fields[3]) != 255:
+        raise ValueError("%s: not an 8-bit binary PPM" % path)
+    w, h = int(fields[1]), int(fields[2])
+    px = np.frombuffer(data, np.uint8, w * h * 3, pos + 1).reshape(h, w, 3)
+    return px.astype(np.float32) / np.float32(255.0)
+
+
+def plant(width=3840, height=2160, env="brown_photostudio_06_1k.hdr", textured=True, prescale=4.0):
+    """BASELINE config 5: indoor_plant_02.obj (22 920 quads = 45 840 triangles) with its MTL file,
+    HDR environment.  addObjectsFromFile makes one Material per triangle from the MTL entry of its
+    face (example_scenes.cpp:85-92): Kd as albedo, roughness 1, metalness 0.  The reference leaves
+    the texture assignment commented out (example_scenes.cpp:111); `textured` attaches the plant's
+    colour map (the 1024x1024 version, stored as PPM) to every one of those materials, all sharing
+    one copy of the texels.  Vertices are scaled by `prescale` at load: at the file's own scale a
+    tenth of the triangles fall under the absolute |det| < 1e-4 rejection (triangle.cpp:16)."""
+    sc = Scene()
+    frm, at = (-2.0, 22.0, 62.0), (-2.0, 15.0, 0.0)
+    focus = float(np.linalg.norm(np.array(at, np.float32) - np.array(frm, np.float32)).astype(np.float32))
+    sc.setSimpleCamera(frm, at, (0, 1, 0), 40, width, height, 0.05, focus)
+    if env:
+        sc.add_ibl_file(asset(env), also_env=True)
+    default = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(0.64, 0.64, 0.64), roughness=1.0, metalness=0.0)
+    first = sc.n_materials
+    sc.addObjectsFromFile(asset("indoor_plant_02.obj"), default, Transform(), prescale=prescale)
+    last = sc.n_materials - 1
+    if textured and last >= first:
+        sc.set_image_texture(first, read_ppm(asset("indoor_plant_2_COL_1k.ppm")))
+        if last > first:
+            sc.share_texture(first, first + 1, last)
     return sc
 
 

@@ -88,6 +88,36 @@ def test_veach_mis_sphere_lights():
     check_images(gpu, cpu, 16)
 
 
+def test_plant_config5_reduced():
+    """BASELINE configs[4] at reduced size: indoor_plant_02.obj with one material per triangle
+    (45 841 materials), all sharing the plant's colour map, HDR environment; image parity and
+    bit-exact primary hits (ids and distances; the oracle reports
+    texture coordinates where the library reports barycentrics, the image covers those)."""
+    sc = scenes.plant(128, 72)
+    flat = sc.initKdTree().flatten(1)
+    d = flat.desc.contents
+    assert d.n_objects == 45840 and d.n_materials == 45841 and d.n_textures == 1
+    dev = DeviceScene(flat)
+    p = render_params(128, 72, 3, 3, max_depth=5, seed=5)
+    gpu = np.zeros((72, 128, 3), np.float32)
+    rs = dev.render(p, gpu)
+    cpu, crs, _, _ = orc.oracle_render(flat.desc, p, 0, threads=16)
+    check_images(gpu, cpu, 9)
+    assert rs.paths == crs.paths == 128 * 72 * 9
+    o, dd = orc.camera_rays(flat.desc, 128, 72, seed=2)
+    n = len(o)
+    tmin, tmax = np.zeros(n, np.float32), np.full(n, 1e5, np.float32)
+    for any_hit in (False, True):
+        prim, t, u, v = dev.intersect(o, dd, tmin, tmax, any_hit=any_hit)
+        want = orc.oracle_intersect(flat.desc, o, dd, tmin, tmax, any_hit)
+        hit = want["prim"] >= 0
+        assert np.array_equal(prim >= 0, hit)
+        assert np.array_equal(prim[hit], want["prim"][hit])
+        assert np.array_equal(t[hit].view(np.uint32), want["t"][hit].view(np.uint32))
+    assert hit.mean() > 0.05
+    dev.close()
+
+
 def test_transparent_textured_and_transformed():
     """Dielectric (reflect/refract by Fresnel), checker and image textures, rotated meshes, depth 8."""
     sc, w, h = cases.make_scene("transformed")

@@ -150,6 +150,22 @@ def test_hdr_loader(built):
         Scene().add_ibl_file(scenes.asset("cornell-box.obj"))
 
 
+def test_plant_obj_mtl_one_material_per_triangle(built):
+    """indoor_plant_02.obj: 22 920 quads with an MTL file -> 45 840 triangles, one Material per
+    triangle (example_scenes.cpp:85-92), no lights; the colour map is stored once."""
+    sc = scenes.plant(64, 36)
+    assert sc.n_objects == 45840
+    assert sc.n_materials == 45841 and sc.n_lights == 1  # the environment
+    m = sc.material(7)
+    assert tuple(round(x, 2) for x in m.albedo) == (0.64, 0.64, 0.64) and m.roughness == 1.0 and m.metalness == 0.0
+    assert m.texture == 0
+    flat = sc.initKdTree().flatten(1)
+    d = flat.desc.contents
+    assert d.n_textures == 1 and d.textures[0].width == 1024 and d.textures[0].height == 1024
+    mats = np.ctypeslib.as_array(d.obj_material, (d.n_objects,))
+    assert len(np.unique(mats)) == 45840
+
+
 def test_missing_obj_reports_error(built):
     sc = Scene()
     m = sc.CreateMaterial()

@@ -1,7 +1,7 @@
 """Whole-frame rate of mrt_render on one of the scene factories (not the bench.py contract: a tool
 for the other BASELINE size classes).
 
-usage: python tools/render_bench.py [--scene cornell|bunny_pair|million_bunny|veach] [--spp-x 16 --spp-y 4] [--depth 5]
+usage: python tools/render_bench.py [--scene cornell|bunny_pair|million_bunny|veach|plant] [--spp-x 16 --spp-y 4] [--depth 5]
 """
 import argparse
 import os
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     a = ap.parse_args()
     factory = {"cornell": scenes.cornell, "bunny_pair": scenes.bunny_pair, "million_bunny": scenes.million_bunny,
-               "veach": scenes.veach_mi}[a.scene]
+               "veach": scenes.veach_mi, "plant": scenes.plant}[a.scene]
     t0 = time.time()
     sc = factory(a.width, a.height)
     tree = sc.initKdTree()
