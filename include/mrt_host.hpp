@@ -290,15 +290,28 @@ class HIPRenderer : public ImageRenderer
     uint32_t seed = 1;
     void init( std::string& imageName, vec2 resolution, Scene* scene ) override;
     void destroy() override;
-    void run() override;
+    void run() override; // the whole spp_x * spp_y grid in one go
     const std::vector<float>& linearSum() const { return m_sum; } // [h][w][3] radiance sums
     const std::vector<float>& image() const { return m_image; }   // averaged + gamma 2.2
     mrt_render_stats stats {};
     double seconds = 0;
 
+    // Progressive accumulation, the accumulate-and-display loop of the reference's viewer
+    // (realtime/Renderer.cpp:57-110: m_accumulationData += frame; shown = accumulated /
+    // m_frameIndex) over sample ranges of the one stratified grid: Render(n) adds the next n
+    // sample indices to the sums and refreshes image() with the average of the samples so far.
+    // Returns false once the grid is exhausted.  A checkpoint holds the sums and the position, so
+    // a frame can be resumed by another renderer (same resolution, grid and seed) or process.
+    bool Render( uint32_t n_samples );
+    void resetAccumulation();
+    uint32_t samplesDone() const { return m_next; }
+    bool saveCheckpoint( const char* filename ) const;
+    bool loadCheckpoint( const char* filename );
+
   private:
     KdTree* m_kdTree = nullptr;
     uint32_t m_w = 0, m_h = 0;
+    uint32_t m_next = 0; // first sample index not rendered yet
     std::vector<float> m_sum, m_image;
 };
 

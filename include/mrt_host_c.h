@@ -80,6 +80,11 @@ void mrth_flat_free( void* flat );
 
 /* HIPRenderer: init, run, destroy (mrt_host.hpp) */
 int mrth_intersect_kdtree( void* scene, void* tree, const float* o3, const float* d3, float tmin, float tmax, int shadow, float* out4 );
+/* HIPRenderer::Render in steps of samples_per_step sample indices; with checkpoint_path the renderer
+ * is checkpointed after checkpoint_after steps, destroyed and resumed from the file by a new one.
+ * Returns the number of steps, -1 on failure. */
+int mrth_hip_render_progressive( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, uint32_t samples_per_step,
+                                 int checkpoint_after, const char* checkpoint_path, float* rgb_sum, mrt_render_stats* stats );
 int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, float* rgb_sum, mrt_render_stats* stats, double* seconds );
 
 #ifdef __cplusplus

@@ -6,6 +6,7 @@
 
 #include <cstring>
 #include <exception>
+#include <stdexcept>
 #include <string>
 
 using namespace mrt;
@@ -334,6 +335,48 @@ int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, 
         if ( seconds ) *seconds = r.seconds;
         r.destroy();
         return 0;
+    } );
+}
+
+// The same frame rendered progressively, samples_per_step sample indices per HIPRenderer::Render
+// call.  With checkpoint_path, the renderer is checkpointed after `checkpoint_after` steps,
+// destroyed, and a new one resumes from the file.  Returns the number of Render calls made.
+int mrth_hip_render_progressive( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, uint32_t samples_per_step,
+                                 int checkpoint_after, const char* checkpoint_path, float* rgb_sum, mrt_render_stats* stats ) {
+    return guarded( [&] {
+        auto make = [&]( HIPRenderer& r ) {
+            r.spp_x    = spp_x;
+            r.spp_y    = spp_y;
+            r.maxDepth = max_depth;
+            r.seed     = seed;
+            r.device   = device;
+            std::string name;
+            r.init( name, vec2 { (float)w, (float)h }, static_cast<Scene*>( scene ) );
+        };
+        std::unique_ptr<HIPRenderer> r( new HIPRenderer );
+        make( *r );
+        int steps = 0;
+        mrt_render_stats total {};
+        bool more = true;
+        while ( more ) {
+            more = r->Render( samples_per_step );
+            steps++;
+            if ( more && checkpoint_path && steps == checkpoint_after ) {
+                if ( !r->saveCheckpoint( checkpoint_path ) ) throw std::runtime_error( "cannot write the checkpoint" );
+                total = r->stats;
+                r->destroy();
+                r.reset( new HIPRenderer );
+                make( *r );
+                if ( !r->loadCheckpoint( checkpoint_path ) ) throw std::runtime_error( "cannot resume from the checkpoint" );
+            }
+        }
+        std::memcpy( rgb_sum, r->linearSum().data(), r->linearSum().size() * sizeof( float ) );
+        if ( stats ) {
+            *stats = r->stats;
+            stats->paths += total.paths, stats->rays_closest += total.rays_closest, stats->rays_any += total.rays_any, stats->rays_mis += total.rays_mis;
+        }
+        r->destroy();
+        return steps;
     } );
 }
 

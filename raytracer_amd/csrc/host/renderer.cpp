@@ -4,7 +4,9 @@
 
 #include <chrono>
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 
 namespace mrt {
@@ -61,28 +63,83 @@ void HIPRenderer::destroy() {
     m_image.clear();
 }
 
-void HIPRenderer::run() {
-    auto t0 = std::chrono::steady_clock::now();
+void HIPRenderer::resetAccumulation() {
+    std::fill( m_sum.begin(), m_sum.end(), 0.f );
+    m_next = 0;
+}
+
+bool HIPRenderer::Render( uint32_t n_samples ) {
+    const uint32_t total = (uint32_t)( spp_x * spp_y );
+    if ( m_next >= total || n_samples == 0 ) return false;
     mrt_render_params p {};
     p.width        = m_w;
     p.height       = m_h;
     p.spp_x        = (uint32_t)spp_x;
     p.spp_y        = (uint32_t)spp_y;
-    p.sample_begin = 0;
-    p.sample_end   = (uint32_t)( spp_x * spp_y );
+    p.sample_begin = m_next;
+    p.sample_end   = n_samples < total - m_next ? m_next + n_samples : total;
     p.max_depth    = (uint32_t)maxDepth;
     p.seed         = seed;
     p.row_begin    = 0;
     p.row_end      = m_h;
-    mrt_status st  = mrt_render( m_kdTree->device_scene, &p, m_sum.data(), MRT_BUF_HOST, nullptr, &stats );
+    mrt_render_stats rs {};
+    mrt_status st = mrt_render( m_kdTree->device_scene, &p, m_sum.data(), MRT_BUF_HOST, nullptr, &rs );
     if ( st != MRT_OK ) throw std::runtime_error( std::string( "mrt_render: " ) + mrt_last_error() );
-    // average + gamma (CPURenderer.cpp:64-69)
-    const float spp = (float)( spp_x * spp_y );
+    m_next = p.sample_end;
+    stats.paths += rs.paths, stats.rays_closest += rs.rays_closest, stats.rays_any += rs.rays_any, stats.rays_mis += rs.rays_mis;
+    stats.generate_ms += rs.generate_ms, stats.extend_ms += rs.extend_ms, stats.shade_ms += rs.shade_ms, stats.connect_ms += rs.connect_ms;
+    // average over the samples so far + gamma (CPURenderer.cpp:64-69, realtime/Renderer.cpp:86-92)
+    const float spp = (float)m_next;
     for ( size_t i = 0; i < m_sum.size(); i++ )
         m_image[i] = powf( m_sum[i] / spp, 1.0f / 2.2 );
+    return m_next < total;
+}
+
+void HIPRenderer::run() {
+    auto t0 = std::chrono::steady_clock::now();
+    resetAccumulation();
+    stats = mrt_render_stats {};
+    Render( (uint32_t)( spp_x * spp_y ) );
     seconds = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
     std::printf( "Rendering took %gs\n", seconds );
     if ( !m_imageName.empty() ) savePPM( ( m_imageName + ".ppm" ).c_str(), m_image.data(), m_w, m_h );
+}
+
+namespace {
+struct CheckpointHeader {
+    char magic[8]; // "MRTCKPT1"
+    uint32_t width, height, spp_x, spp_y, seed, max_depth, next, reserved;
+};
+} // namespace
+
+bool HIPRenderer::saveCheckpoint( const char* filename ) const {
+    CheckpointHeader h {};
+    std::memcpy( h.magic, "MRTCKPT1", 8 );
+    h.width = m_w, h.height = m_h, h.spp_x = (uint32_t)spp_x, h.spp_y = (uint32_t)spp_y, h.seed = seed, h.max_depth = (uint32_t)maxDepth, h.next = m_next;
+    FILE* f = std::fopen( filename, "wb" );
+    if ( !f ) return false;
+    bool ok = std::fwrite( &h, sizeof( h ), 1, f ) == 1 && std::fwrite( m_sum.data(), sizeof( float ), m_sum.size(), f ) == m_sum.size();
+    return ( std::fclose( f ) == 0 ) && ok;
+}
+
+bool HIPRenderer::loadCheckpoint( const char* filename ) {
+    FILE* f = std::fopen( filename, "rb" );
+    if ( !f ) return false;
+    CheckpointHeader h {};
+    bool ok = std::fread( &h, sizeof( h ), 1, f ) == 1 && std::memcmp( h.magic, "MRTCKPT1", 8 ) == 0;
+    // a checkpoint continues only the frame it was taken from
+    ok = ok && h.width == m_w && h.height == m_h && h.spp_x == (uint32_t)spp_x && h.spp_y == (uint32_t)spp_y && h.seed == seed &&
+         h.max_depth == (uint32_t)maxDepth && h.next <= (uint32_t)( spp_x * spp_y );
+    std::vector<float> sum( m_sum.size() );
+    ok = ok && std::fread( sum.data(), sizeof( float ), sum.size(), f ) == sum.size();
+    std::fclose( f );
+    if ( !ok ) return false;
+    m_sum.swap( sum );
+    m_next = h.next;
+    const float spp = m_next ? (float)m_next : 1.f;
+    for ( size_t i = 0; i < m_sum.size(); i++ )
+        m_image[i] = powf( m_sum[i] / spp, 1.0f / 2.2 );
+    return true;
 }
 
 } // namespace mrt

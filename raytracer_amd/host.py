@@ -171,6 +171,21 @@ class Scene:
         return img, st, sec.value
 
 
+    def hip_render_progressive(self, width, height, spp_x, spp_y, samples_per_step, max_depth=5, seed=1, device=0,
+                               checkpoint_after=-1, checkpoint_path=None):
+        """HIPRenderer::Render in steps (the viewer's accumulation loop over sample ranges); with
+        checkpoint_path the renderer is checkpointed after `checkpoint_after` steps, destroyed, and
+        a fresh one resumes from the file.  Returns the radiance sums, statistics, step count."""
+        img = np.zeros((height, width, 3), np.float32)
+        st = abi.RenderStats()
+        r = abi.host().mrth_hip_render_progressive(self._h, width, height, spp_x, spp_y, max_depth, seed, device, samples_per_step,
+                                                   checkpoint_after, str(checkpoint_path).encode() if checkpoint_path else None,
+                                                   _fp(img), C.byref(st))
+        if r < 0:
+            raise MrtError(abi.host().mrth_last_error().decode())
+        return img, st, r
+
+
 class KdTree:
     def __init__(self, scene, n_threads=0):
         self.scene = scene

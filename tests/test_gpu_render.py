@@ -374,6 +374,25 @@ def test_hip_renderer_and_single_ray_host_api():
     dev.close()
 
 
+def test_progressive_accumulation_and_checkpoint_resume(tmp_path):
+    """HIPRenderer::Render adds sample ranges of the one stratified grid (the viewer's
+    accumulate loop); a frame resumed from a checkpoint by a new renderer is bit-identical to the
+    uninterrupted progressive frame, and both match the one-call frame up to the order in which
+    the per-range sums are added."""
+    sc = scenes.small_bunny(48, 48, env_pixels=scenes.synthetic_env())
+    whole, st, _ = sc.hip_render(48, 48, 4, 4, max_depth=4, seed=11)
+    steps, st_p, n = sc.hip_render_progressive(48, 48, 4, 4, 5, max_depth=4, seed=11)
+    assert n == 4  # 5 + 5 + 5 + 1 samples
+    assert st_p.paths == st.paths == 48 * 48 * 16
+    assert st_p.rays_closest == st.rays_closest and st_p.rays_any == st.rays_any
+    assert np.allclose(steps, whole, rtol=2e-6, atol=1e-6)
+    ck = tmp_path / "frame.ckpt"
+    resumed, st_r, n_r = sc.hip_render_progressive(48, 48, 4, 4, 5, max_depth=4, seed=11, checkpoint_after=2, checkpoint_path=ck)
+    assert n_r == 4 and os.path.getsize(ck) == 40 + 48 * 48 * 3 * 4
+    assert np.array_equal(resumed, steps)
+    assert st_r.paths == st.paths
+
+
 def test_render_trace_counters():
     """MRT_RENDER_TRACE_STATS: the traversal visits the render kernels count themselves agree with
     the oracle's counters for the reference traversal where the kernels do the same walk
