@@ -158,6 +158,12 @@ def test_sample_ranges_and_row_ranges_tile_the_frame():
     small = np.zeros_like(full)
     dev.render(render_params(64, 64, 4, 4, seed=3, paths_per_pass=64 * 5), small)
     assert np.allclose(small, full, rtol=2e-6, atol=1e-7)
+    # whole-frame passes of 3 sample indices each (tiled passes, path ids tile-major), and passes of
+    # 16 rows x all samples (tiled, two tile rows per pass)
+    for cap in (64 * 64 * 3, 64 * 16 * 16):
+        part = np.zeros_like(full)
+        dev.render(render_params(64, 64, 4, 4, seed=3, paths_per_pass=cap), part)
+        assert np.allclose(part, full, rtol=2e-6, atol=1e-7)
     # accumulation: rendering twice doubles the sums
     twice = full.copy()
     dev.render(render_params(64, 64, 4, 4, seed=3), twice)
