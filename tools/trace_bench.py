@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--subdiv", type=int, default=0, help="midpoint subdivisions of the meshes (x4 triangles each)")
     ap.add_argument("--octant", type=int, default=0, help="group secondary rays by direction octant within runs of this many rays")
     ap.add_argument("--tile", action="store_true", help="order the primary rays in 8x8 pixel tiles")
+    ap.add_argument("--second", action="store_true", help="also time second-generation rays, unsorted and sorted by origin")
     ap.add_argument("--small", action="store_true", help="69k-triangle single bunny instead of the bench scene")
     a = ap.parse_args()
     W, H = 1920, 1080
@@ -104,6 +105,53 @@ def main():
             name, m, int((p >= 0).sum()), ms, m / ms / 1e3, st.inner / m, st.leaves / m, st.refs / m,
             st.prim_tests / m, b_ray, b_ray * m / ms / 1e6, digest), flush=True)
     print("total %.3f ms" % total_ms)
+    if a.second:
+        # second-generation rays (leaving the hit points of the bounce rays): in the order of their
+        # parents, and sorted by the Morton code of their origin
+        m = len(so)
+        p2, t2 = dev.intersect(so, sd, torch.zeros(m, device="cuda"), torch.full((m,), 1e5, device="cuda"))[:2]
+        h2 = p2 >= 0
+        w = torch.randn((m, 3), device="cuda", generator=g)
+        w = w / w.norm(dim=1, keepdim=True)
+        flip = (w * sd).sum(1) > 0
+        w[flip] = -w[flip]
+        o2 = (so + t2[:, None] * sd + 1e-3 * w)[h2].contiguous()
+        d2 = w[h2].contiguous()
+        lo, hi = o2.min(0).values, o2.max(0).values
+        q = ((o2 - lo) / (hi - lo + 1e-9) * 1023).long().clamp(0, 1023)
+        code = torch.zeros(len(o2), dtype=torch.long, device="cuda")
+        for b in range(10):
+            for k in range(3):
+                code |= ((q[:, k] >> b) & 1) << (3 * b + k)
+        order = torch.sort(code).indices
+        for name, oo, dd in (("second", o2, d2), ("second, origin-sorted", o2[order].contiguous(), d2[order].contiguous())):
+            mm = len(oo)
+            tmin = torch.zeros(mm, device="cuda")
+            tmax = torch.full((mm,), 1e4, device="cuda")
+            st = dev.intersect(oo, dd, tmin, tmax, stats=True)[4]
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(a.reps):
+                dev.intersect(oo, dd, tmin, tmax)
+            ev1.record()
+            torch.cuda.synchronize()
+            ms = ev0.elapsed_time(ev1) / a.reps
+            print("%-22s n=%d  %.3f ms  %.1f Mrays/s | per ray: inner %.1f leaves %.2f tests %.2f" % (
+                name, mm, ms, mm / ms / 1e3, st.inner / mm, st.leaves / mm, st.prim_tests / mm), flush=True)
+        # the same rays eight times over: a list long enough that the kernel's tail does not count
+        o8, d8 = o2.repeat(8, 1).contiguous(), d2.repeat(8, 1).contiguous()
+        mm = len(o8)
+        tmin, tmax = torch.zeros(mm, device="cuda"), torch.full((mm,), 1e4, device="cuda")
+        dev.intersect(o8, d8, tmin, tmax)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        dev.intersect(o8, d8, tmin, tmax)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1)
+        print("%-22s n=%d  %.3f ms  %.1f Mrays/s" % ("second x8", mm, ms, mm / ms / 1e3), flush=True)
     # the same bounce batch handed over as host buffers (PCIe both ways inside the call)
     ho, hd = so.cpu().numpy(), sd.cpu().numpy()
     m = len(ho)
