@@ -269,6 +269,26 @@ def test_scene_create_rejects_malformed_descriptions(built):
     assert lib.mrt_scene_create(None, 0, C.byref(h)) == 1
 
 
+def test_product_path_fails_loudly_without_a_gpu(built):
+    """No CPU fallback: on a machine without a HIP device the scene cannot be created and the
+    renderer raises; nothing is routed through the oracle."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from raytracer_amd.host import DeviceScene, MrtError
+    sc = scenes.cornell(16, 16)
+    flat = sc.initKdTree().flatten(1)
+    h = C.c_void_p()
+    st = abi.hip().mrt_scene_create(flat.desc, 0, C.byref(h))
+    assert st == 2 and not h.value, (st, abi.hip().mrt_last_error())
+    with pytest.raises(MrtError):
+        DeviceScene(flat)
+    with pytest.raises(MrtError):
+        sc.hip_render(16, 16, 1, 1)
+    with pytest.raises(MrtError):
+        sc.hip_render_progressive(16, 16, 2, 2, 1)
+
+
 def test_intersect_and_render_reject_null_arguments(built):
     lib = abi.hip()
     assert lib.mrt_intersect(None, 0, None, None, 0, 0, None, None) == 1
