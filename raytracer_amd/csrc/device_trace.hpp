@@ -279,13 +279,15 @@ MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
 // wave-wide votes and a block barrier); blockDim.x must be MRT_TRACE_BLOCK; `lds` must hold
 // MRT_TRACE_LDS_WORDS 32-bit words.
 //
-// Dealing: the list is cut into eight contiguous parts, one per XCD (workgroups go to the XCDs
-// round-robin, so blockIdx.x & 7 names the XCD), each with a counter in `deal` (eight counters
-// MRT_DEAL_STRIDE words apart, zero at launch).  A wave draws the next 64-ray chunk of its XCD's
-// part, and of the following parts once that one is exhausted.  The rays in flight on one XCD are
-// therefore consecutive in the list - for path tracing: neighbouring pixels - and share the tree
-// nodes and primitives they pull through that XCD's L2; and no wave is left with a longer share
-// than the others.
+// Dealing: the list is cut into runs of MRT_DEAL_RUN 64-ray chunks, dealt round-robin to eight
+// parts, one per XCD (workgroups go to the XCDs round-robin, so blockIdx.x & 7 names the XCD), each
+// with a counter in `deal` (eight counters MRT_DEAL_STRIDE words apart, zero at launch).  A wave
+// draws the next chunk of its XCD's part, and of the following parts once that one is exhausted.
+// The rays in flight on one XCD are therefore consecutive in the list - for path tracing:
+// neighbouring pixels - and share the tree nodes and primitives they pull through that XCD's L2;
+// the eight XCDs work on neighbouring runs, so what one of them brought into the memory-side cache
+// serves the others; and no wave is left with a longer share than the others.
+#define MRT_DEAL_RUN 256u
 #define MRT_DEAL_STRIDE 32u
 #define MRT_DEAL_WORDS ( 8u * MRT_DEAL_STRIDE )
 template <bool ANY, bool BOOL_ONLY, bool STATS, class IO>
@@ -308,7 +310,6 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     lds_f4* pl_lds    = (lds_f4*)( lds + MRT_LDS_PL ) + threadIdx.x;
 
     const uint32_t n_chunks = ( n + 63u ) >> 6;
-    const uint32_t per_part = ( n_chunks + 7u ) >> 3;
     uint32_t part_try = 0;          // parts found exhausted so far, counted from this XCD's own
     uint32_t chunk = 0, left = 0;   // first ray of the wave's current chunk, rays not yet taken from it
     bool more      = n_chunks != 0; // some part may still have chunks
@@ -349,8 +350,8 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 uint32_t got        = 0;
                 if ( __lane_id() == 0 ) got = atomicAdd( deal + part * MRT_DEAL_STRIDE, 1u );
                 got                 = (uint32_t)__builtin_amdgcn_readfirstlane( (int)got );
-                const uint32_t c    = part * per_part + got;
-                if ( got < per_part && c < n_chunks ) chunk = c << 6, left = 64u;
+                const uint32_t c    = ( ( got / MRT_DEAL_RUN ) * 8u + part ) * MRT_DEAL_RUN + got % MRT_DEAL_RUN;
+                if ( c < n_chunks ) chunk = c << 6, left = 64u;
                 else part_try++;
             }
             more = left != 0;
