@@ -122,6 +122,7 @@ def main():
     t_begin = time.perf_counter()
     rays_closest = rays_any = paths = 0
     kms = {"generate": 0.0, "extend": 0.0, "shade": 0.0, "connect": 0.0}
+    mis_ms = 0.0  # the part of "connect" spent in the MIS rays' kernel
     for _ in range(args.steps):
         rs = step()
         rays_closest += rs.rays_closest
@@ -131,6 +132,7 @@ def main():
         kms["extend"] += rs.extend_ms
         kms["shade"] += rs.shade_ms
         kms["connect"] += rs.connect_ms
+        mis_ms += rs.connect_mis_ms
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -219,14 +221,16 @@ def main():
         def own_bytes(ts, n):
             return 52.0 * n + 8.0 * ts.inner + 8.0 * ts.leaves + 4.0 * ts.refs + 36.0 * ts.prim_tests
         ext_bytes = own_bytes(own.trace[0], n_ext)
-        con_bytes = own_bytes(own.trace[1], n_sh) + own_bytes(own.trace[2], n_mis)
         per_step = {k: v / args.steps for k, v in kms.items()}
         n_bounces = MAX_DEPTH + 1
-        if per_step["extend"] >= per_step["connect"]:
-            name, byts, ms, launches = "extend_kernel", ext_bytes, per_step["extend"], n_bounces
-        else:
-            # (the bench scene has no emissive object, so MIS rays go through the occlusion variant)
-            name, byts, ms, launches = "connect_shadow_kernel+connect_mis_occlusion_kernel", con_bytes, per_step["connect"], 2 * n_bounces
+        # the three traversal kernels, each with its summed device time per step; the roofline is
+        # that of the one with the most (the bench scene has no emissive object, so its MIS rays
+        # go through the occlusion variant)
+        cands = [("extend_kernel", ext_bytes, per_step["extend"]),
+                 ("connect_shadow_kernel", own_bytes(own.trace[1], n_sh), per_step["connect"] - mis_ms / args.steps),
+                 ("connect_mis_occlusion_kernel", own_bytes(own.trace[2], n_mis), mis_ms / args.steps)]
+        name, byts, ms = max(cands, key=lambda c: c[2])
+        launches = n_bounces
         achieved = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "kernel": name, "launches_per_step": launches,

@@ -217,6 +217,7 @@ typedef struct mrt_render_stats {
      * kernels actually visited for [0] continuation rays, [1] shadow rays, [2] MIS rays */
     mrt_trace_stats trace[3];
     uint64_t rays_mis; /* the part of rays_closest that were MIS rays (integrator.cpp:104-109) */
+    double connect_mis_ms; /* the part of connect_ms spent on the MIS rays' kernel */
 } mrt_render_stats;
 
 /* initKdTree + the Scene the reference hands to its integrator (kdtree.h:35, scene.h:19-43),
