@@ -3,9 +3,9 @@
 // It computes what CPURenderer::run does for one camera sample (rendering/CPURenderer.cpp:46-62):
 // camera sample, SimpleCamera::get_ray, then Pathtracer::trace_ray (integrator.cpp:128-211) with
 // directIllumination (integrator.cpp:69-120).  One path = one camera sample; all per-path state is
-// struct-of-arrays in HBM, indexed by the path id (pass_path below: tile, sample, pixel in tile),
-// so that the 64 lanes of a wave hold an 8x8 pixel tile at one sample index (coherent primary
-// rays, coalesced state access) and consecutive 64-path chunks the same tile at the next samples.  Work lists are queues of path ids; the kernels are
+// struct-of-arrays in HBM, indexed by the path id (pass_path below: pixels tile by tile, the
+// samples of a pixel together), so that the 64 lanes of a wave hold 64 samples of one pixel
+// (coherent rays, coalesced state access) and consecutive chunks the neighbouring pixels.  Work lists are queues of path ids; the kernels are
 //   generate        camera sample + primary ray for every id
 //   extend          closest-hit traversal of the continuation ray of every live path
 //   shade           everything of one loop iteration of trace_ray that needs no further ray:
@@ -118,19 +118,19 @@ MRT_DEV void pass_pixel( const PassInfo& pi, uint32_t p_local, uint32_t& x, uint
     y = pi.row_begin + r;
 }
 
-// Path id of sample s_local of pixel p_local, and back.  In a tiled pass the samples of one tile
-// are numbered together: (tile, sample, pixel in tile), so consecutive 64-path chunks are the
-// same 64 pixels at consecutive sample indices and the rays in flight at any time come from a few
-// tiles of the image.  Otherwise (sample, pixel).
+// Path id of sample s_local of pixel p_local, and back.  In a tiled pass the samples of one pixel
+// are numbered together and the pixels tile by tile: (pixel, sample).  A 64-path chunk is then
+// 64 samples of one pixel - rays that start at (nearly) the same point and descend the tree
+// together - and the rays in flight at any time come from a few tiles of the image.  Otherwise
+// (sample, pixel).
 MRT_DEV uint32_t pass_path( const PassInfo& pi, uint32_t s_local, uint32_t p_local ) {
-    if ( pass_tiled( pi ) ) return ( ( ( p_local >> 6 ) * pi.n_samples + s_local ) << 6 ) | ( p_local & 63u );
+    if ( pass_tiled( pi ) ) return p_local * pi.n_samples + s_local;
     return s_local * pi.n_pixels + p_local;
 }
 MRT_DEV void pass_split( const PassInfo& pi, uint32_t id, uint32_t& s_local, uint32_t& p_local ) {
     if ( pass_tiled( pi ) ) {
-        const uint32_t chunk = id >> 6, tile = chunk / pi.n_samples;
-        s_local = chunk - tile * pi.n_samples;
-        p_local = ( tile << 6 ) | ( id & 63u );
+        p_local = id / pi.n_samples;
+        s_local = id - p_local * pi.n_samples;
         return;
     }
     s_local = id / pi.n_pixels;
@@ -488,8 +488,39 @@ __global__ void __launch_bounds__( 256 ) mis_resolve_kernel( DTrace tr, DShade s
 }
 
 // ------------------------------------------------------------------------------------------------
-// One thread per pixel of the pass: radiances of its samples are added in sample order
-// (CPURenderer.cpp:60: pixel_color += trace_ray(...)), then added to the image sum.
+// Radiances of a pixel's samples are added in sample order (CPURenderer.cpp:60: pixel_color +=
+// trace_ray(...)), then added to the image sum.
+// Tiled pass (a pixel's samples are consecutive paths): one wave per pixel loads 64 samples at a
+// time, coalesced, and every lane adds them up in order through lane reads.
+__global__ void __launch_bounds__( 256 ) accumulate_pixel_kernel( PathState ps, PassInfo pi, float* __restrict__ rgb_sum ) {
+    const uint32_t p = ( blockIdx.x * blockDim.x + threadIdx.x ) >> 6, lane = threadIdx.x & 63u;
+    if ( p >= pi.n_pixels ) return;
+    V3 sum = mk3( 0.f );
+    for ( uint32_t base = 0; base < pi.n_samples; base += 64u ) {
+        const uint32_t s = base + lane;
+        V3 L             = mk3( 0.f );
+        if ( s < pi.n_samples ) {
+            const uint32_t id = pass_path( pi, s, p );
+            L                 = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
+            fold_pending( ps, id, L );
+        }
+        const uint32_t cnt = pi.n_samples - base < 64u ? pi.n_samples - base : 64u;
+        for ( uint32_t k = 0; k < cnt; k++ ) {
+            sum.x = sum.x + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( L.x ), (int)k ) );
+            sum.y = sum.y + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( L.y ), (int)k ) );
+            sum.z = sum.z + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( L.z ), (int)k ) );
+        }
+    }
+    if ( lane != 0 ) return;
+    uint32_t px, py;
+    pass_pixel( pi, p, px, py );
+    float* dst = rgb_sum + 3 * (size_t)( py * pi.width + px );
+    dst[0] += sum.x;
+    dst[1] += sum.y;
+    dst[2] += sum.z;
+}
+
+// Any other pass (the samples of a pixel are n_pixels apart): one thread per pixel.
 __global__ void __launch_bounds__( 256 ) accumulate_kernel( PathState ps, PassInfo pi, float* __restrict__ rgb_sum ) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if ( p >= pi.n_pixels ) return;
