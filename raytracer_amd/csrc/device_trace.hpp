@@ -20,7 +20,7 @@
 //     here the planes are tested when a ray is fetched (nearest plane, first one on ties; for
 //     any-hit rays the first accepted plane) and merged with the tree result when the ray retires.
 //
-// Execution model: streaming traversal.  The waves draw 64-ray chunks of the ray list from
+// Execution model: streaming traversal.  The waves draw chunks (MRT_CHUNK rays) of the ray list from
 // counters (one per eighth of the list, see trace_stream) and every
 // lane is a small state machine (idle / node / primitive test).  One trip of
 // the wave's loop performs, for every lane, the work that depends on the loads issued in the trip
@@ -279,7 +279,7 @@ MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
 // wave-wide votes and a block barrier); blockDim.x must be MRT_TRACE_BLOCK; `lds` must hold
 // MRT_TRACE_LDS_WORDS 32-bit words.
 //
-// Dealing: the list is cut into runs of MRT_DEAL_RUN 64-ray chunks, dealt round-robin to eight
+// Dealing: the list is cut into runs of MRT_DEAL_RUN chunks of MRT_CHUNK rays, dealt round-robin to eight
 // parts, one per XCD (workgroups go to the XCDs round-robin, so blockIdx.x & 7 names the XCD), each
 // with a counter in `deal` (eight counters MRT_DEAL_STRIDE words apart, zero at launch).  A wave
 // draws the next chunk of its XCD's part, and of the following parts once that one is exhausted.
@@ -287,7 +287,12 @@ MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
 // neighbouring pixels - and share the tree nodes and primitives they pull through that XCD's L2;
 // the eight XCDs work on neighbouring runs, so what one of them brought into the memory-side cache
 // serves the others; and no wave is left with a longer share than the others.
-#define MRT_DEAL_RUN 256u
+#ifndef MRT_CHUNK
+#define MRT_CHUNK 128u // rays a wave draws at a time
+#endif
+#ifndef MRT_DEAL_RUN
+#define MRT_DEAL_RUN 128u
+#endif
 #define MRT_DEAL_STRIDE 32u
 #define MRT_DEAL_WORDS ( 8u * MRT_DEAL_STRIDE )
 template <bool ANY, bool BOOL_ONLY, bool STATS, class IO>
@@ -309,7 +314,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     };
     lds_f4* pl_lds    = (lds_f4*)( lds + MRT_LDS_PL ) + threadIdx.x;
 
-    const uint32_t n_chunks = ( n + 63u ) >> 6;
+    const uint32_t n_chunks = ( n + ( MRT_CHUNK - 1u ) ) / MRT_CHUNK;
     uint32_t part_try = 0;          // parts found exhausted so far, counted from this XCD's own
     uint32_t chunk = 0, left = 0;   // first ray of the wave's current chunk, rays not yet taken from it
     bool more      = n_chunks != 0; // some part may still have chunks
@@ -351,14 +356,14 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 if ( __lane_id() == 0 ) got = atomicAdd( deal + part * MRT_DEAL_STRIDE, 1u );
                 got                 = (uint32_t)__builtin_amdgcn_readfirstlane( (int)got );
                 const uint32_t c    = ( ( got / MRT_DEAL_RUN ) * 8u + part ) * MRT_DEAL_RUN + got % MRT_DEAL_RUN;
-                if ( c < n_chunks ) chunk = c << 6, left = 64u;
+                if ( c < n_chunks ) chunk = c * MRT_CHUNK, left = MRT_CHUNK;
                 else part_try++;
             }
             more = left != 0;
             const uint32_t take = n_idle < left ? n_idle : left;
             if ( state == MRT_ST_IDLE ) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi( (uint32_t)( idle >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)idle, 0u ) );
-                const uint32_t idx  = chunk + ( 64u - left ) + rank;
+                const uint32_t idx  = chunk + ( MRT_CHUNK - left ) + rank;
                 if ( rank < take && idx < n ) {
                     float ray_tmin, ray_tmax;
                     io.load( idx, tag, o, d, ray_tmin, ray_tmax );
