@@ -490,34 +490,35 @@ __global__ void __launch_bounds__( 256 ) mis_resolve_kernel( DTrace tr, DShade s
 // ------------------------------------------------------------------------------------------------
 // Radiances of a pixel's samples are added in sample order (CPURenderer.cpp:60: pixel_color +=
 // trace_ray(...)), then added to the image sum.
-// Tiled pass (a pixel's samples are consecutive paths): one wave per pixel loads 64 samples at a
-// time, coalesced, and every lane adds them up in order through lane reads.
+// Tiled pass (a pixel's samples are consecutive paths): a block takes 64 pixels; its waves load 64
+// samples of one pixel at a time (coalesced) into an LDS tile, then one lane per pixel and colour
+// channel adds that pixel's 64 values in order.
 __global__ void __launch_bounds__( 256 ) accumulate_pixel_kernel( PathState ps, PassInfo pi, float* __restrict__ rgb_sum ) {
-    const uint32_t p = ( blockIdx.x * blockDim.x + threadIdx.x ) >> 6, lane = threadIdx.x & 63u;
-    if ( p >= pi.n_pixels ) return;
-    V3 sum = mk3( 0.f );
+    __shared__ float tile[3][64][65];
+    const uint32_t p0 = blockIdx.x * 64u, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    float sum = 0.f; // of pixel p0 + lane, channel `wave` (waves 0..2)
     for ( uint32_t base = 0; base < pi.n_samples; base += 64u ) {
-        const uint32_t s = base + lane;
-        V3 L             = mk3( 0.f );
-        if ( s < pi.n_samples ) {
-            const uint32_t id = pass_path( pi, s, p );
-            L                 = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
-            fold_pending( ps, id, L );
+        for ( uint32_t r = wave; r < 64u; r += 4u ) {
+            const uint32_t p = p0 + r, s = base + lane;
+            V3 L             = mk3( 0.f );
+            if ( p < pi.n_pixels && s < pi.n_samples ) {
+                const uint32_t id = pass_path( pi, s, p );
+                L                 = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
+                fold_pending( ps, id, L );
+            }
+            tile[0][r][lane] = L.x, tile[1][r][lane] = L.y, tile[2][r][lane] = L.z;
         }
+        __syncthreads();
         const uint32_t cnt = pi.n_samples - base < 64u ? pi.n_samples - base : 64u;
-        for ( uint32_t k = 0; k < cnt; k++ ) {
-            sum.x = sum.x + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( L.x ), (int)k ) );
-            sum.y = sum.y + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( L.y ), (int)k ) );
-            sum.z = sum.z + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( L.z ), (int)k ) );
-        }
+        if ( wave < 3u )
+            for ( uint32_t k = 0; k < cnt; k++ )
+                sum = sum + tile[wave][lane][k];
+        __syncthreads();
     }
-    if ( lane != 0 ) return;
+    if ( wave >= 3u || p0 + lane >= pi.n_pixels ) return;
     uint32_t px, py;
-    pass_pixel( pi, p, px, py );
-    float* dst = rgb_sum + 3 * (size_t)( py * pi.width + px );
-    dst[0] += sum.x;
-    dst[1] += sum.y;
-    dst[2] += sum.z;
+    pass_pixel( pi, p0 + lane, px, py );
+    rgb_sum[3 * (size_t)( py * pi.width + px ) + wave] += sum;
 }
 
 // Any other pass (the samples of a pixel are n_pixels apart): one thread per pixel.
