@@ -104,11 +104,11 @@ struct DStats {
 //                     miss reports as t
 //   plane record      the plane hit found when the ray was fetched (prim, t, u, v)
 #ifndef MRT_STACK_LDS
-#define MRT_STACK_LDS 5
+#define MRT_STACK_LDS 7
 #endif
 #define MRT_TRACE_BLOCK 256
 #ifndef MRT_TRACE_WAVES
-#define MRT_TRACE_WAVES 6 // waves per SIMD the traversal kernels are compiled for (register budget)
+#define MRT_TRACE_WAVES 5 // waves per SIMD the traversal kernels are compiled for (LDS: five blocks per CU)
 #endif
 #define MRT_LDS_XF 0
 #define MRT_LDS_STACK ( MRT_LDS_XF + MRT_XF_LDS * 12 )
