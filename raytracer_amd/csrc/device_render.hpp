@@ -228,7 +228,7 @@ struct ExtendIO {
 // and primitive tests into stats[0..3].
 template <bool STATS>
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
-    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
     trace_stream<false, false, STATS>( tr, lp, io, n_ptr ? *n_ptr : n_max, deal, st );
@@ -397,7 +397,7 @@ struct ShadowIO {
 
 template <bool STATS>
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
-    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( true )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
     trace_stream<true, true, STATS>( tr, lp, io, *count, deal, st );
@@ -420,7 +420,7 @@ struct MisIO {
 
 template <bool STATS>
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
-    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
     trace_stream<false, false, STATS>( tr, lp, io, *count, deal, st );
@@ -449,7 +449,7 @@ struct MisOcclusionIO {
 
 template <bool STATS>
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_occlusion_kernel( DTrace tr, MisOcclusionIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
-    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( true )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
     trace_stream<true, true, STATS>( tr, lp, io, *count, deal, st );

@@ -40,7 +40,7 @@
 #define MRT_STACK_MAX 64
 #define MRT_ACNE_EPS 1e-4f
 #ifndef MRT_XF_LDS
-#define MRT_XF_LDS 64 // transforms kept in LDS (12 floats each); the rest are read from HBM
+#define MRT_XF_LDS 16 // transforms kept in LDS (12 floats each); the rest are read from HBM
 #endif
 #ifndef MRT_REFILL_MIN
 #define MRT_REFILL_MIN 16 // idle lanes that trigger a refill of the wave
@@ -97,25 +97,27 @@ struct DStats {
 // LDS of a traversal block (MRT_TRACE_BLOCK lanes).  Everything a lane touches rarely lives here
 // instead of in registers, slot-major so that the lanes of a wave fall on distinct banks:
 //   transform table   inv (9) + translation (3) of the first MRT_XF_LDS transforms
-//   stack             the first MRT_STACK_LDS deferred nodes of every lane (deeper ones in scratch)
-//   object-space ray  origin and direction under the lane's current transform
+//   stack             the first deferred nodes of every lane (deeper ones in scratch, and every
+//                     scratch access waits for all the gathers in flight: the more entries fit
+//                     here the better)
 //   hit record        the accepted hit of the current leaf (prim | outside << 31, u, v); until
 //                     there is one, the u slot keeps the tmax the ray came with, which is what a
 //                     miss reports as t
 //   plane record      the plane hit found when the ray was fetched (prim, t, u, v)
+// A traversal that only answers "occluded or not" (BOOL_ONLY) keeps no records and gives their
+// space to the stack.  Sized for six blocks per CU (160 KB / 6 = 6826 words).
 #ifndef MRT_STACK_LDS
-#define MRT_STACK_LDS 7
+#define MRT_STACK_LDS 9
+#endif
+#ifndef MRT_STACK_LDS_BOOL
+#define MRT_STACK_LDS_BOOL 12
 #endif
 #define MRT_TRACE_BLOCK 256
 #ifndef MRT_TRACE_WAVES
-#define MRT_TRACE_WAVES 5 // waves per SIMD the traversal kernels are compiled for (LDS: five blocks per CU)
+#define MRT_TRACE_WAVES 6 // waves per SIMD the traversal kernels are compiled for (register budget)
 #endif
-#define MRT_LDS_XF 0
-#define MRT_LDS_STACK ( MRT_LDS_XF + MRT_XF_LDS * 12 )
-#define MRT_LDS_XR ( MRT_LDS_STACK + MRT_STACK_LDS * MRT_TRACE_BLOCK * 2 )  // 3 x float2 per lane
-#define MRT_LDS_OUT ( MRT_LDS_XR + 3 * MRT_TRACE_BLOCK * 2 )              // float2 + float per lane
-#define MRT_LDS_PL ( MRT_LDS_OUT + MRT_TRACE_BLOCK * 3 )                  // float4 per lane
-#define MRT_TRACE_LDS_WORDS ( MRT_LDS_PL + MRT_TRACE_BLOCK * 4 )
+#define MRT_TRACE_LDS_WORDS( BOOL_ONLY ) \
+    ( MRT_XF_LDS * 12 + ( ( BOOL_ONLY ) ? MRT_STACK_LDS_BOOL * MRT_TRACE_BLOCK * 2 : MRT_STACK_LDS * MRT_TRACE_BLOCK * 2 + MRT_TRACE_BLOCK * 7 ) )
 
 typedef __attribute__( ( address_space( 3 ) ) ) uint32_t lds_u32;
 typedef __attribute__( ( address_space( 3 ) ) ) float lds_f32;
@@ -277,7 +279,7 @@ MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
 // ANY: shadow-ray semantics.  BOOL_ONLY (with ANY): only `found` is meaningful, so a ray that hits
 // a plane retires without entering the tree.  Every thread of the grid must call this (it uses
 // wave-wide votes and a block barrier); blockDim.x must be MRT_TRACE_BLOCK; `lds` must hold
-// MRT_TRACE_LDS_WORDS 32-bit words.
+// MRT_TRACE_LDS_WORDS( BOOL_ONLY ) 32-bit words.
 //
 // Dealing: the list is cut into runs of MRT_DEAL_RUN chunks of MRT_CHUNK rays, dealt round-robin to eight
 // parts, one per XCD (workgroups go to the XCDs round-robin, so blockIdx.x & 7 names the XCD), each
@@ -297,22 +299,17 @@ MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
 #define MRT_DEAL_WORDS ( 8u * MRT_DEAL_STRIDE )
 template <bool ANY, bool BOOL_ONLY, bool STATS, class IO>
 MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t n, uint32_t* deal, DStats& st ) {
-    const lds_f32* xf_lds = (const lds_f32*)( lds + MRT_LDS_XF );
-    stage_transforms( s, (lds_f32*)( lds + MRT_LDS_XF ) );
-    lds_u2* stack_lds = (lds_u2*)( lds + MRT_LDS_STACK ) + threadIdx.x;
-    lds_f2* xr_lds    = (lds_f2*)( lds + MRT_LDS_XR ) + threadIdx.x;   // + k * MRT_TRACE_BLOCK, k = 0..2
-    lds_f2* out_lds   = (lds_f2*)( lds + MRT_LDS_OUT ) + threadIdx.x;  // (prim bits, u)
-    lds_f32* outv_lds = (lds_f32*)( lds + MRT_LDS_OUT + MRT_TRACE_BLOCK * 2 ) + threadIdx.x;
-    auto put_xr       = [&]( V3 ro, V3 rd ) {
-        v2f p;
-        p.x = ro.x, p.y = ro.y;
-        xr_lds[0] = p;
-        p.x = ro.z, p.y = rd.x;
-        xr_lds[MRT_TRACE_BLOCK] = p;
-        p.x = rd.y, p.y = rd.z;
-        xr_lds[2 * MRT_TRACE_BLOCK] = p;
-    };
-    lds_f4* pl_lds    = (lds_f4*)( lds + MRT_LDS_PL ) + threadIdx.x;
+    constexpr int NST          = BOOL_ONLY ? MRT_STACK_LDS_BOOL : MRT_STACK_LDS;
+    constexpr uint32_t LDS_STACK = MRT_XF_LDS * 12, LDS_OUT = LDS_STACK + NST * MRT_TRACE_BLOCK * 2, LDS_PL = LDS_OUT + MRT_TRACE_BLOCK * 3;
+    const lds_f32* xf_lds = (const lds_f32*)lds;
+    stage_transforms( s, (lds_f32*)lds );
+    lds_u2* stack_lds = (lds_u2*)( lds + LDS_STACK ) + threadIdx.x;
+    // the records below exist only when !BOOL_ONLY
+    lds_f2* out_lds   = (lds_f2*)( lds + LDS_OUT ) + threadIdx.x; // (prim bits, u)
+    lds_f32* outv_lds = (lds_f32*)( lds + LDS_OUT + MRT_TRACE_BLOCK * 2 ) + threadIdx.x;
+    lds_f4* pl_lds    = (lds_f4*)( lds + LDS_PL ) + threadIdx.x;
+    V3 xro = mk3( 0.f ), xrd = mk3( 0.f ); // object-space ray under the lane's current transform
+    auto put_xr = [&]( V3 ro, V3 rd ) { xro = ro, xrd = rd; };
 
     const uint32_t n_chunks = ( n + ( MRT_CHUNK - 1u ) ) / MRT_CHUNK;
     uint32_t part_try = 0;          // parts found exhausted so far, counted from this XCD's own
@@ -334,13 +331,13 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     bool has       = false; // the current leaf has produced a hit (record in LDS, distance = tmax)
     bool has_pl    = false; // a plane was hit at fetch time (record in LDS)
     uint32_t pl_tests = 0;  // planes the reference would have tested for this ray (counters only)
-    v2u stack_deep[MRT_STACK_MAX - MRT_STACK_LDS];
+    v2u stack_deep[MRT_STACK_MAX - NST];
     int sp = 0;
     auto push = [&]( uint32_t what, float upto ) {
         v2u e;
         e.x = what, e.y = __float_as_uint( upto );
-        if ( sp < MRT_STACK_LDS ) stack_lds[sp * MRT_TRACE_BLOCK] = e;
-        else stack_deep[sp - MRT_STACK_LDS] = e;
+        if ( sp < NST ) stack_lds[sp * MRT_TRACE_BLOCK] = e;
+        else stack_deep[sp - NST] = e;
         sp++;
     };
 
@@ -368,7 +365,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                     float ray_tmin, ray_tmax;
                     io.load( idx, tag, o, d, ray_tmin, ray_tmax );
                     xr_id    = 0;
-                    {
+                    if ( !BOOL_ONLY ) {
                         v2f m;
                         m.x = __uint_as_float( 0xffffffffu ), m.y = ray_tmax;
                         *out_lds = m;
@@ -389,11 +386,13 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                             btmax = t; // accepted: later planes must be at least as near,
                             // and replace this one only if strictly nearer
                             bool better = true;
-                            if ( has_pl ) {
-                                const v4f cur = *pl_lds;
-                                better           = t < cur.y;
+                            if ( !BOOL_ONLY ) {
+                                if ( has_pl ) {
+                                    const v4f cur = *pl_lds;
+                                    better        = t < cur.y;
+                                }
+                                if ( better ) *pl_lds = mk4( __uint_as_float( po ), t, u, v );
                             }
-                            if ( better ) *pl_lds = mk4( __uint_as_float( po ), t, u, v );
                             has_pl = true;
                             if ( ANY ) {
                                 if ( STATS ) pl_tests = k + 1;
@@ -424,7 +423,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                         if ( STATS ) st.tests += pl_tests;
                         DHit h;
                         h.prim = -1, h.t = ray_tmax, h.u = h.v = 0.f, h.outside = 0;
-                        if ( has_pl ) {
+                        if ( !BOOL_ONLY && has_pl ) {
                             const v4f r = *pl_lds;
                             h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
                         }
@@ -505,8 +504,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 put_xr( oo, od );
                 xr_id = xf;
             }
-            const v2f x0 = xr_lds[0], x1 = xr_lds[MRT_TRACE_BLOCK], x2 = xr_lds[2 * MRT_TRACE_BLOCK];
-            const V3 origin = mk3( x0.x, x0.y, x1.x ), dir = mk3( x1.y, x2.x, x2.y );
+            const V3 origin = xro, dir = xrd;
             float t = 0.f, u = 0.f, v = 0.f, det = 0.f;
             bool outside = true, hit;
             if ( ( flags & 3u ) == MRT_PRIM_TRI ) {
@@ -517,7 +515,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             // accepted hits shrink the interval whether or not they are kept
             const bool keep = hit & ( ANY ? !( flags & MRT_PRIM_EMISSIVE ) : ( !has | ( t < tmax ) ) );
             tmax            = hit ? t : tmax;
-            if ( keep ) {
+            if ( !BOOL_ONLY && keep ) {
                 v2f m;
                 m.x = __uint_as_float( obj | ( outside ? 0x80000000u : 0u ) ), m.y = u;
                 *out_lds  = m;
@@ -537,8 +535,8 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             if ( sp != 0 ) {
                 --sp;
                 v2u e;
-                if ( sp < MRT_STACK_LDS ) e = stack_lds[sp * MRT_TRACE_BLOCK];
-                else e = stack_deep[sp - MRT_STACK_LDS];
+                if ( sp < NST ) e = stack_lds[sp * MRT_TRACE_BLOCK];
+                else e = stack_deep[sp - NST];
                 a         = b;
                 b         = __uint_as_float( e.y );
                 node      = e.x & 0x3fffffffu;
@@ -550,20 +548,23 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         if ( retire ) {
             // a shadow ray that found an occluder in the tree never reaches the planes
             if ( STATS && !( ANY && has ) ) st.tests += pl_tests;
-            const v2f rec = *out_lds;
             DHit h;
-            h.prim    = has ? (int32_t)( __float_as_uint( rec.x ) & 0x7fffffffu ) : -1;
-            h.t       = has ? tmax : rec.y;
-            h.u       = has ? rec.y : 0.f;
-            h.v       = has ? *outv_lds : 0.f;
-            h.outside = has ? __float_as_uint( rec.x ) >> 31 : 0u;
+            h.prim = has ? 0 : -1, h.t = tmax, h.u = h.v = 0.f, h.outside = 0;
             bool found = has;
-            if ( has_pl ) {
-                const v4f r = *pl_lds;
-                // a plane replaces a tree hit only if strictly nearer (never for an any-hit ray)
-                if ( !has || ( !ANY && r.y < h.t ) ) {
-                    h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
-                    found  = true;
+            if ( !BOOL_ONLY ) {
+                const v2f rec = *out_lds;
+                h.prim    = has ? (int32_t)( __float_as_uint( rec.x ) & 0x7fffffffu ) : -1;
+                h.t       = has ? tmax : rec.y;
+                h.u       = has ? rec.y : 0.f;
+                h.v       = has ? *outv_lds : 0.f;
+                h.outside = has ? __float_as_uint( rec.x ) >> 31 : 0u;
+                if ( has_pl ) {
+                    const v4f r = *pl_lds;
+                    // a plane replaces a tree hit only if strictly nearer (never for an any-hit ray)
+                    if ( !has || ( !ANY && r.y < h.t ) ) {
+                        h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
+                        found  = true;
+                    }
                 }
             }
             io.store( tag, found, h );

@@ -346,7 +346,7 @@ struct BatchIO {
 
 template <bool ANY, bool STATS>
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) trace_batch_kernel( DTrace s, BatchIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
-    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS];
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
     trace_stream<ANY, false, STATS>( s, lp, io, n, deal, st );
