@@ -239,6 +239,25 @@ mrt_status mrt_intersect( mrt_scene* scene,
                           void* stream,
                           mrt_trace_stats* stats );
 
+/* mrt_intersect for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same results as mrt_intersect with MRT_BUF_DEVICE and stats == NULL: all eight ray arrays and
+ * four hit arrays are device memory, the call is asynchronous on `stream`.  It calls no hipMalloc /
+ * hipFree: the traversal's chunk-deal counters live in a static device array of
+ * MRT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends
+ * (its address on a device is looked up when the first mrt_scene is created there).  Every call on
+ * one GPU, whatever the scene handle or stream, shares that GPU's array: calls that overlap in
+ * time on one GPU race (rays are skipped or traced twice) -- order them on one stream or with
+ * events.  n > MRT_NOALLOC_MAX_RAYS is rejected with MRT_ERR_UNSUPPORTED. */
+#define MRT_NOALLOC_MAX_RAYS 0x7fffffffull
+#define MRT_NOALLOC_SCRATCH_BYTES 1088u
+mrt_status mrt_intersect_noalloc( mrt_scene* scene,
+                                  uint64_t n,
+                                  const mrt_rays* rays,
+                                  const mrt_hits* hits,
+                                  uint32_t flags,
+                                  void* stream );
+
 /* The per-sample body of CPURenderer::run (rendering/CPURenderer.cpp:46-62): camera sample,
  * SimpleCamera::get_ray, Pathtracer::trace_ray (integrator.cpp:128-211), summed per pixel.
  * rgb_sum is [height][width][3] floats of LINEAR radiance SUMS (not averaged, not gamma

@@ -117,6 +117,8 @@ def hip():
         lib.mrt_intersect.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Rays), C.POINTER(Hits), C.c_uint32, C.c_uint32,
                                       C.c_void_p, C.POINTER(TraceStats)]
         lib.mrt_intersect.restype = C.c_int32
+        lib.mrt_intersect_noalloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Rays), C.POINTER(Hits), C.c_uint32, C.c_void_p]
+        lib.mrt_intersect_noalloc.restype = C.c_int32
         lib.mrt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_uint32, C.c_void_p,
                                    C.POINTER(RenderStats)]
         lib.mrt_render.restype = C.c_int32

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <memory>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -188,6 +189,7 @@ mrt_status build_tree_records( const mrt_scene_desc* d, std::vector<uint4>& node
 static mrt_status upload_shading( const mrt_scene_desc* d, mrt_scene* s ); // render_host.inc
 namespace {
 void free_workspace( RenderWorkspace& w );
+mrt_status scratch_for_device( int device, uint32_t** out ); // with mrt_intersect_noalloc
 }
 mrt_scene::~mrt_scene() {
     if ( d_stats ) (void)hipFree( d_stats );
@@ -240,6 +242,12 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     HIP_TRY( hipSetDevice( device ) );
     int n_cus = 0;
     HIP_TRY( hipDeviceGetAttribute( &n_cus, hipDeviceAttributeMultiprocessorCount, device ) );
+    {
+        // set-up of mrt_intersect_noalloc: this device's address of the static scratch array
+        uint32_t* unused = nullptr;
+        mrt_status ss    = scratch_for_device( device, &unused );
+        if ( ss != MRT_OK ) return ss;
+    }
 
     bool no_emitters = true;
     std::vector<float4> prims( MRT_PRIM_Q * (size_t)d->n_objects, make_float4( 0.f, 0.f, 0.f, 0.f ) );
@@ -434,6 +442,65 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
         stats->prim_tests = h[3];
     }
     else if ( placement == MRT_BUF_HOST ) { HIP_TRY( hipStreamSynchronize( stream ) ); }
+    return MRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mrt_intersect_noalloc: mrt_intersect on device buffers for callers that cannot allocate.
+//
+// The chunk-deal counters of the streaming traversal (scratch that mrt_intersect keeps in a
+// hipMalloc'ed per-scene buffer) live in a static device array instead.  Every GPU the library runs
+// on holds its own copy of the array at its own address until the process ends; the address is
+// looked up once per device (scratch_for_device, called from mrt_scene_create with that device
+// current) and only that pointer, never the array's name, is used in host code.
+// ------------------------------------------------------------------------------------------------
+#define MRT_NOALLOC_SCRATCH_WORDS ( 16u + MRT_DEAL_WORDS ) // 8 x u64 traversal counters (unused here), then the deal counters
+static __device__ __align__( 256 ) uint32_t scratch[MRT_NOALLOC_SCRATCH_WORDS];
+static_assert( MRT_NOALLOC_SCRATCH_WORDS * sizeof( uint32_t ) == MRT_NOALLOC_SCRATCH_BYTES, "mrt.h states the size of the static scratch array" );
+
+namespace {
+constexpr int MRT_MAX_DEVICES = 64;
+uint32_t* g_scratch_ptr[MRT_MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;
+
+// Address of `scratch` on `device`, which must be the current device.
+mrt_status scratch_for_device( int device, uint32_t** out ) {
+    if ( device < 0 || device >= MRT_MAX_DEVICES ) return fail( MRT_ERR_UNSUPPORTED, "device index beyond the library's table (64)" );
+    std::lock_guard<std::mutex> lock( g_scratch_mutex );
+    if ( !g_scratch_ptr[device] ) {
+        void* p = nullptr;
+        HIP_TRY( hipGetSymbolAddress( &p, HIP_SYMBOL( scratch ) ) );
+        if ( !p ) return fail( MRT_ERR_DEVICE, "hipGetSymbolAddress returned NULL for the static scratch array" );
+        g_scratch_ptr[device] = (uint32_t*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return MRT_OK;
+}
+} // namespace
+
+extern "C" mrt_status mrt_intersect_noalloc( mrt_scene* sc, uint64_t n, const mrt_rays* rays, const mrt_hits* hits, uint32_t flags, void* stream_ ) {
+    if ( !sc || !rays || !hits ) return fail( MRT_ERR_INVALID, "NULL argument" );
+    if ( flags != MRT_CLOSEST_HIT && flags != MRT_ANY_HIT ) return fail( MRT_ERR_INVALID, "flags must be MRT_CLOSEST_HIT or MRT_ANY_HIT" );
+    if ( n == 0 ) return MRT_OK;
+    if ( n > MRT_NOALLOC_MAX_RAYS ) return fail( MRT_ERR_UNSUPPORTED, "mrt_intersect_noalloc: batch larger than MRT_NOALLOC_MAX_RAYS (2^31 - 1) rays" );
+    const float* in[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmin, rays->tmax };
+    for ( const float* p : in )
+        if ( !p ) return fail( MRT_ERR_INVALID, "NULL ray array" );
+    if ( !hits->prim || !hits->t || !hits->u || !hits->v ) return fail( MRT_ERR_INVALID, "NULL hit array" );
+    HIP_TRY( hipSetDevice( sc->device ) );
+    uint32_t* sp = nullptr;
+    mrt_status ss = scratch_for_device( sc->device, &sp ); // a table look-up after mrt_scene_create
+    if ( ss != MRT_OK ) return ss;
+    hipStream_t stream = (hipStream_t)stream_;
+    // the deal counters must start at zero; the array keeps the last call's contents
+    HIP_TRY( hipMemsetAsync( sp, 0, MRT_NOALLOC_SCRATCH_WORDS * sizeof( uint32_t ), stream ) );
+    const BatchIO io { in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], hits->prim, hits->t, hits->u, hits->v };
+    const dim3 block( MRT_TRACE_BLOCK );
+    if ( flags == MRT_ANY_HIT )
+        hipLaunchKernelGGL( ( trace_batch_kernel<true, false> ), dim3( trace_grid_blocks( trace_batch_kernel<true, false>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, sp + 16, (unsigned long long*)sp );
+    else
+        hipLaunchKernelGGL( ( trace_batch_kernel<false, false> ), dim3( trace_grid_blocks( trace_batch_kernel<false, false>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, sp + 16, (unsigned long long*)sp );
+    HIP_TRY( hipGetLastError() );
     return MRT_OK;
 }
 

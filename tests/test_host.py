@@ -177,7 +177,7 @@ def test_missing_obj_reports_error(built):
 def test_hip_library_exports_every_declared_symbol(built):
     hdr = open(os.path.join(ROOT, "include", "mrt.h")).read()
     names = set(re.findall(r"^(?:mrt_status|void|const char\*|int32_t)\s+(mrt_[a-z_]+)\s*\(", hdr, re.M))
-    assert {"mrt_scene_create", "mrt_scene_destroy", "mrt_intersect", "mrt_render", "mrt_resolve", "mrt_last_error",
+    assert {"mrt_scene_create", "mrt_scene_destroy", "mrt_intersect", "mrt_intersect_noalloc", "mrt_render", "mrt_resolve", "mrt_last_error",
             "mrt_version", "mrt_debug_eval"} <= names
     lib = abi.hip()
     for n in names:
