@@ -218,6 +218,7 @@ typedef struct mrt_render_stats {
     mrt_trace_stats trace[3];
     uint64_t rays_mis; /* the part of rays_closest that were MIS rays (integrator.cpp:104-109) */
     double connect_mis_ms; /* the part of connect_ms spent on the MIS rays' kernel */
+    uint64_t passes;       /* passes the call was cut into (every kernel class is launched max_depth + 1 times per pass) */
 } mrt_render_stats;
 
 /* initKdTree + the Scene the reference hands to its integrator (kdtree.h:35, scene.h:19-43),

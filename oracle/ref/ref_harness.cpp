@@ -3,7 +3,10 @@
 // C-callable shim around the UNMODIFIED reference translation units that build in this
 // container without any stand-in header:
 //   kdtree.cpp ray.cpp Object.cpp intersection.cpp shapes/{triangle,sphere,plane,cube}.cpp
-//   sampling/{sampling,sampler,stratified}.cpp bsdf.cpp Camera.cpp
+//   sampling/{sampling,sampler,stratified}.cpp bsdf.cpp Camera.cpp LightDistribution.cpp image.cpp
+//   (+ libs/lodepng-master/lodepng.cpp, which image.cpp calls), and the header-only
+//   tiny_obj_loader.h (its implementation is instantiated here exactly as scene.cpp:1 does),
+//   textures.hpp, and the inline random_dir / CoordinateSystem of sampling.h / defines.h.
 // (Material.cpp, Light.cpp, integrator.cpp, scene.cpp and example_scenes.cpp include
 // Light.h, which needs <stb_image.h>; that header is not in the image, so those units are
 // treated as unbuildable and are NOT part of this library.)
@@ -12,7 +15,9 @@
 // reference functions, and copies results into flat arrays so that tests/golden/make_golden.py
 // can record golden vectors. It is compiled by oracle/Makefile into oracle/_ref/libmrt_ref.so,
 // which exists only in the build container (the reference sources do not travel).
+#define TINYOBJLOADER_IMPLEMENTATION // scene.cpp:1 (scene.cpp itself is not buildable here)
 #include "Camera.h"
+#include "LightDistribution.h"
 #include "Object.h"
 #include "bsdf.hpp"
 #include "kdtree.h"
@@ -23,6 +28,9 @@
 #include "shapes/plane.h"
 #include "shapes/sphere.h"
 #include "shapes/triangle.h"
+#include "textures.hpp"
+
+#include <lodepng.h>
 
 #include <cstdint>
 #include <cstring>
@@ -540,6 +548,122 @@ void ref_camera_params( void* cam_, float* out12 ) {
     put3( out12 + 3, cam->dXPixel );
     put3( out12 + 6, cam->dYPixel );
     put3( out12 + 9, cam->xDir );
+}
+
+// ---------------------------------------------------------------- textures.hpp:12-125
+// texture::value(u, v, duv) -- the overload Material::eval / sample call (Material.cpp:990-993) --
+// of a checker_texture of two solid colours, under the texture transform built from `xf`.
+void ref_checker_value( const float* even3, const float* odd3, void* xf, int64_t n, const float* uv2, float* out3 ) {
+    checker_texture tex( color3( even3[0], even3[1], even3[2] ), color3( odd3[0], odd3[1], odd3[2] ) );
+    if ( xf ) tex.m_transform = *static_cast<Transform*>( xf );
+    const vec3 duv[2] = { vec3( 0.01f, 0, 0 ), vec3( 0, 0.01f, 0 ) };
+    const texture* t = &tex; // Material::m_texture is a texture*: the call resolves to the base overload
+    for ( int64_t i = 0; i < n; i++ )
+        put3( out3 + 3 * i, t->value( uv2[2 * i], uv2[2 * i + 1], duv ) );
+}
+// image_texture: the 8-bit RGB image is written as a PNG with the reference's own lodepng and read
+// back through image_texture's constructor (loadPng, image.cpp:14-41).
+int ref_image_value( const char* png_path, int w, int h, const uint8_t* rgb8, void* xf, int64_t n, const float* uv2, float* out3 ) {
+    if ( lodepng_encode24_file( png_path, rgb8, (unsigned)w, (unsigned)h ) ) return -1;
+    image_texture tex( png_path );
+    if ( xf ) tex.m_transform = *static_cast<Transform*>( xf );
+    const vec3 duv[2] = { vec3( 0.01f, 0, 0 ), vec3( 0, 0.01f, 0 ) };
+    const texture* t = &tex; // Material::m_texture is a texture*: the call resolves to the base overload
+    for ( int64_t i = 0; i < n; i++ )
+        put3( out3 + 3 * i, t->value( uv2[2 * i], uv2[2 * i + 1], duv ) );
+    return 0;
+}
+
+// ---------------------------------------------------------------- random_dir (sampling.h:199-211)
+// The function draws five values from the translation unit's thread-local `engine`
+// (defines.h:63-64).  For each row the engine is seeded, the five uniform01(engine) values it will
+// deliver are recorded in drawing order, the engine is seeded again and random_dir is called: the
+// recorded values and the result pin the arithmetic and which draw feeds which component.
+void ref_random_dir( int64_t n, const float* normal3, const uint32_t* seed, float* draws5, float* out3 ) {
+    for ( int64_t i = 0; i < n; i++ ) {
+        engine.seed( seed[i] );
+        uniform01.reset();
+        for ( int k = 0; k < 5; k++ )
+            draws5[5 * i + k] = uniform01( engine );
+        engine.seed( seed[i] );
+        uniform01.reset();
+        put3( out3 + 3 * i, random_dir( v3( normal3 + 3 * i ) ) );
+    }
+}
+// CoordinateSystem (defines.h:150-156)
+void ref_coordinate_system( int64_t n, const float* v1_3, float* v2_3, float* v3_3 ) {
+    for ( int64_t i = 0; i < n; i++ ) {
+        vec3 a, b;
+        CoordinateSystem( v3( v1_3 + 3 * i ), &a, &b );
+        put3( v2_3 + 3 * i, a );
+        put3( v3_3 + 3 * i, b );
+    }
+}
+
+// ---------------------------------------------------------------- LightDistribution.cpp:5-12
+// UniformLightDistribution over a scene with n_lights lights (only lights.size() is read), then
+// lookup(p)->SampleDiscrete(u, &pdf) as integrator.cpp:152-160 calls it.
+void ref_uniform_light_distribution( int n_lights, int64_t m, const float* u, int32_t* off, float* pdf ) {
+    Scene scene;
+    scene.lights.assign( (size_t)n_lights, nullptr );
+    UniformLightDistribution d( &scene );
+    const Distribution1D* dist = d.lookup( point3( 0 ) );
+    for ( int64_t i = 0; i < m; i++ )
+        off[i] = dist->SampleDiscrete( u[i], &pdf[i] );
+}
+
+// ---------------------------------------------------------------- tiny_obj_loader.h v1.0.6
+// LoadObj exactly as readObjToTriangleMesh calls it (scene.cpp:179-187), then the per-face walk of
+// addObjectsFromFile (example_scenes.cpp:32-69) flattened into arrays: for every face its three
+// positions, normals (when the file has any) and texture coordinates (when it has any) and its
+// material id; for every MTL material ior, diffuse, emission, specular.
+// Two-call protocol: with null outputs only the counts are returned.
+int ref_obj_load( const char* obj_path, const char* mtl_dir, int64_t* n_faces, int64_t* n_materials, int32_t* has_normals, int32_t* has_texcoords,
+                  float* pos9, float* nrm9, float* tex6, int32_t* material_id, float* mtl10 ) {
+    tinyobj::attrib_t attrib;
+    std::vector<tinyobj::shape_t> shapes;
+    std::vector<tinyobj::material_t> materials;
+    std::string err;
+    if ( !tinyobj::LoadObj( &attrib, &shapes, &materials, &err, obj_path, mtl_dir ) ) return -1;
+    int64_t f_total = 0;
+    for ( size_t s = 0; s < shapes.size(); s++ ) {
+        size_t index_offset = 0;
+        for ( size_t f = 0; f < shapes[s].mesh.num_face_vertices.size(); f++ ) {
+            int fv = shapes[s].mesh.num_face_vertices[f];
+            if ( fv != 3 ) return -2; // LoadObj triangulates by default
+            if ( pos9 ) {
+                for ( int v = 0; v < fv; v++ ) {
+                    tinyobj::index_t idx = shapes[s].mesh.indices[index_offset + v];
+                    for ( int k = 0; k < 3; k++ )
+                        pos9[9 * f_total + 3 * v + k] = attrib.vertices[3 * idx.vertex_index + k];
+                    if ( !attrib.normals.empty() )
+                        for ( int k = 0; k < 3; k++ )
+                            nrm9[9 * f_total + 3 * v + k] = attrib.normals[3 * idx.normal_index + k];
+                    if ( !attrib.texcoords.empty() )
+                        for ( int k = 0; k < 2; k++ )
+                            tex6[6 * f_total + 2 * v + k] = attrib.texcoords[2 * idx.texcoord_index + k];
+                }
+                material_id[f_total] = shapes[s].mesh.material_ids[f];
+            }
+            index_offset += fv;
+            f_total++;
+        }
+    }
+    *n_faces       = f_total;
+    *n_materials   = (int64_t)materials.size();
+    *has_normals   = attrib.normals.empty() ? 0 : 1;
+    *has_texcoords = attrib.texcoords.empty() ? 0 : 1;
+    if ( mtl10 )
+        for ( size_t m = 0; m < materials.size(); m++ ) {
+            float* d = mtl10 + 10 * m;
+            d[0]     = materials[m].ior;
+            for ( int k = 0; k < 3; k++ ) {
+                d[1 + k] = materials[m].diffuse[k];
+                d[4 + k] = materials[m].emission[k];
+                d[7 + k] = materials[m].specular[k];
+            }
+        }
+    return 0;
 }
 
 } // extern "C"

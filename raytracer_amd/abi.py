@@ -94,7 +94,8 @@ class RenderParams(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("paths", C.c_uint64),
                 ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("connect_ms", C.c_double), ("generate_ms", C.c_double),
-                ("trace", TraceStats * 3), ("rays_mis", C.c_uint64), ("connect_mis_ms", C.c_double)]
+                ("trace", TraceStats * 3), ("rays_mis", C.c_uint64), ("connect_mis_ms", C.c_double),
+                ("passes", C.c_uint64)]
 
 
 _hip = None

@@ -373,7 +373,7 @@ int mrth_hip_render_progressive( void* scene, uint32_t w, uint32_t h, int spp_x,
         std::memcpy( rgb_sum, r->linearSum().data(), r->linearSum().size() * sizeof( float ) );
         if ( stats ) {
             *stats = r->stats;
-            stats->paths += total.paths, stats->rays_closest += total.rays_closest, stats->rays_any += total.rays_any, stats->rays_mis += total.rays_mis;
+            stats->paths += total.paths, stats->rays_closest += total.rays_closest, stats->rays_any += total.rays_any, stats->rays_mis += total.rays_mis, stats->passes += total.passes;
         }
         r->destroy();
         return steps;

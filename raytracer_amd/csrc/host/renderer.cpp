@@ -86,7 +86,7 @@ bool HIPRenderer::Render( uint32_t n_samples ) {
     mrt_status st = mrt_render( m_kdTree->device_scene, &p, m_sum.data(), MRT_BUF_HOST, nullptr, &rs );
     if ( st != MRT_OK ) throw std::runtime_error( std::string( "mrt_render: " ) + mrt_last_error() );
     m_next = p.sample_end;
-    stats.paths += rs.paths, stats.rays_closest += rs.rays_closest, stats.rays_any += rs.rays_any, stats.rays_mis += rs.rays_mis;
+    stats.paths += rs.paths, stats.rays_closest += rs.rays_closest, stats.rays_any += rs.rays_any, stats.rays_mis += rs.rays_mis, stats.passes += rs.passes;
     stats.generate_ms += rs.generate_ms, stats.extend_ms += rs.extend_ms, stats.shade_ms += rs.shade_ms, stats.connect_ms += rs.connect_ms, stats.connect_mis_ms += rs.connect_mis_ms;
     // average over the samples so far + gamma (CPURenderer.cpp:64-69, realtime/Renderer.cpp:86-92)
     const float spp = (float)m_next;

@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
 """Copies the judged summaries of a tools/profile_bench.sh run into profiles/.
 
-usage: tools/collect_profiles.py gpurun_out/prof_r01 r01
+usage: tools/collect_profiles.py gpurun_out/prof_r02 r02 million_bunny
 
-Writes profiles/<tag>_bench_kernel_stats.csv  rocprofv3 --kernel-trace --stats of `python3 bench.py`
-       profiles/<tag>_bench.json              the JSON line that run printed
-       profiles/<tag>_pmc_summary.json        per-kernel counter sums of the --pmc passes (one step)
-       profiles/hbm_traffic.json              bytes per step per kernel, (2*FETCH_SIZE + WRITE_SIZE) KiB:
-                                              FETCH_SIZE is doubled as gfx950 tallies 128-byte read
-                                              requests at 64 bytes; read by bench.py for roofline.traffic
+Writes profiles/<tag>_<workload>_kernel_stats.csv  rocprofv3 --kernel-trace --stats of `python3 bench.py --workload W --no-secondary`
+       profiles/<tag>_<workload>_bench.json        the JSON line that run printed
+       profiles/<tag>_<workload>_pmc_summary.json  per-kernel counter sums of the --pmc passes (one step)
+       profiles/hbm_traffic.json                   per workload and kernel: HBM bytes per launch,
+                                                   (2*FETCH_SIZE + WRITE_SIZE) KiB / dispatches (FETCH_SIZE
+                                                   doubled: gfx950 tallies 128-byte read requests at 64
+                                                   bytes), and the L2 (TCC) hit rate; read by bench.py
 """
-import csv
 import glob
 import json
 import os
@@ -19,32 +19,46 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, tag = sys.argv[1], sys.argv[2]
+src, tag, workload = sys.argv[1], sys.argv[2], sys.argv[3]
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+base = "%s_%s" % (tag, workload)
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
-shutil.copy(stats, os.path.join(dst, tag + "_bench_kernel_stats.csv"))
+shutil.copy(stats, os.path.join(dst, base + "_kernel_stats.csv"))
 line = [l for l in open(os.path.join(src, "bench.log")) if l.startswith('{"metric"')][-1]
-with open(os.path.join(dst, tag + "_bench.json"), "w") as f:
+with open(os.path.join(dst, base + "_bench.json"), "w") as f:
     f.write(line)
-tmp = os.path.join(dst, tag + "_pmc_summary.json")
+tmp = os.path.join(dst, base + "_pmc_summary.json")
 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), src, "--json", tmp], check=True, stdout=subprocess.DEVNULL)
 pmc = json.load(open(tmp))
 
-
-def traffic(k):
-    return (2.0 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0
-
-
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 0 --no-cpu`",
-       "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, summed over the launches of one step",
-       "bytes_per_step": {k: traffic(k) for k in pmc if "FETCH_SIZE" in pmc[k]}}
-for mis in ("connect_mis_occlusion_kernel", "connect_mis_kernel"):  # whichever the scene made the library use
-    if mis in pmc:
-        out["bytes_per_step"]["connect_shadow_kernel+" + mis] = traffic("connect_shadow_kernel") + traffic(mis)
-out["fetch_size_kib_per_step"] = {k: pmc[k]["FETCH_SIZE"] for k in pmc if "FETCH_SIZE" in pmc[k]}
-out["write_size_kib_per_step"] = {k: pmc[k]["WRITE_SIZE"] for k in pmc if "WRITE_SIZE" in pmc[k]}
-with open(os.path.join(dst, "hbm_traffic.json"), "w") as f:
-    json.dump(out, f, indent=1)
-print("profiles written for", tag)
+path = os.path.join(dst, "hbm_traffic.json")
+allw = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_* (separate passes) over `python3 bench.py --workload W --no-secondary "
+                  "--steps 1 --warmup 0 --no-cpu`",
+        "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes summed over the launches of the step / number of launches",
+        "workloads": {}}
+if os.path.exists(path):
+    try:
+        old = json.load(open(path))
+        if "workloads" in old:
+            allw["workloads"] = old["workloads"]
+    except Exception:
+        pass
+w = {"tag": tag, "bytes_per_launch": {}, "bytes_per_step": {}, "fetch_size_kib_per_step": {}, "write_size_kib_per_step": {},
+     "dispatches_per_step": {}, "tcc_hit_rate": {}}
+for k, c in pmc.items():
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        continue
+    b = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    w["bytes_per_step"][k] = b
+    w["bytes_per_launch"][k] = b / c["dispatches"]
+    w["dispatches_per_step"][k] = c["dispatches"]
+    w["fetch_size_kib_per_step"][k] = c["FETCH_SIZE"]
+    w["write_size_kib_per_step"][k] = c["WRITE_SIZE"]
+    if c.get("TCC_REQ_sum"):
+        w["tcc_hit_rate"][k] = c["TCC_HIT_sum"] / c["TCC_REQ_sum"]
+allw["workloads"][workload] = w
+with open(path, "w") as f:
+    json.dump(allw, f, indent=1)
+print("profiles written for", tag, workload)
