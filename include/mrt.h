@@ -296,6 +296,10 @@ mrt_status mrt_resolve( mrt_scene* scene,
  *   CAMERA           SimpleCamera::get_ray (Camera.cpp:37-67)   in: s, t, ulens, vlens                         out: origin3, dir3
  *   BSDF_TERMS       RDM_Beckmann, RDM_Fresnel, RDM_G1 (bsdf.cpp:43-58,100-118,141-154)
  *                                                               in: ndoth, alpha, ldoth, ext, int, ddotn       out: D, F, G1
+ *   TEXTURE          texture::value(u, v, duv) (textures.hpp:21-43, 64-125) in: texture, u, v                       out: rgb3
+ *   LIGHT_PICK       UniformLightDistribution::lookup()->SampleDiscrete (LightDistribution.cpp:5-12, sampling.h:86-119)
+ *                                                               in: u                                          out: light index, pdf
+ *   RANDOM_DIR_DRAWS random_dir on five given engine draws      in: normal3, draws5 (drawing order)            out: dir3
  * seq2 = the two 32-bit halves of a PCG32 sequence index, passed as float bit patterns. */
 enum {
     MRT_DBG_MATERIAL_EVAL   = 0,
@@ -306,7 +310,10 @@ enum {
     MRT_DBG_RANDOM_DIR      = 5,
     MRT_DBG_SAMPLER         = 6,
     MRT_DBG_CAMERA          = 7,
-    MRT_DBG_BSDF_TERMS      = 8
+    MRT_DBG_BSDF_TERMS      = 8,
+    MRT_DBG_TEXTURE         = 9,
+    MRT_DBG_LIGHT_PICK      = 10,
+    MRT_DBG_RANDOM_DIR_DRAWS = 11
 };
 mrt_status mrt_debug_eval( mrt_scene* scene, uint32_t fn, uint32_t n, const float* in, uint32_t in_stride, float* out, uint32_t out_stride );
 

@@ -287,6 +287,12 @@ inline V3 texture_value( const Texture& t, float u, float v ) {
     return v3( t.texels + 3 * px );
 }
 
+// UniformLightDistribution::UniformLightDistribution (LightDistribution.cpp:5-8)
+inline Distribution1D* uniform_light_distribution( int n_lights ) {
+    std::vector<float> prob( n_lights, 1.f );
+    return new Distribution1D( &prob[0], int( prob.size() ) );
+}
+
 // ------------------------------------------------------------------ shading scene
 struct ShadeScene : TraceScene {
     std::vector<Shape> light_shapes;
@@ -302,10 +308,7 @@ struct ShadeScene : TraceScene {
             textures.push_back( Texture { t.kind, t.width, t.height, desc->texels ? desc->texels + t.texel_offset : nullptr,
                                           v3( t.even ), v3( t.odd ), xf_from( t.xf ) } );
         }
-        if ( desc->n_lights > 0 ) {
-            std::vector<float> prob( desc->n_lights, 1.f );
-            lightDistrib.reset( new Distribution1D( &prob[0], (int)prob.size() ) );
-        }
+        if ( desc->n_lights > 0 ) lightDistrib.reset( uniform_light_distribution( (int)desc->n_lights ) );
         if ( desc->env_rgb && desc->env_width > 0 )
             envDistrib.reset( new Distribution2D( desc->env_rgb, desc->env_width, desc->env_height ) );
         env_inv = m3_from( desc->env_inv );
@@ -350,10 +353,12 @@ inline V3 random_dir( V3 normal, SamplerIface& smp ) {
     float theta = 2.f * Pi * r1;
     float r     = std::sqrt( 1.f - r2 );
     V3 local    = v3( std::cos( theta ) * r, std::sin( theta ) * r, std::sqrt( r2 ) );
-    // uniform01(engine) - 0.5: float minus double, narrowed to float by the vec3 constructor
-    float rx = (float)( (double)smp.engine01() - 0.5 );
-    float ry = (float)( (double)smp.engine01() - 0.5 );
+    // uniform01(engine) - 0.5: float minus double, narrowed to float by the vec3 constructor.
+    // g++ evaluates the three constructor arguments last to first (recorded from the reference's
+    // own random_dir: the third engine draw feeds z, the fifth x).
     float rz = (float)( (double)smp.engine01() - 0.5 );
+    float ry = (float)( (double)smp.engine01() - 0.5 );
+    float rx = (float)( (double)smp.engine01() - 0.5 );
     V3 randV = v3( rx, ry, rz );
     V3 tangent1 = normalize( cross( normal, randV ) );
     V3 tangent2 = cross( tangent1, normal );

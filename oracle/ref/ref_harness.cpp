@@ -666,4 +666,27 @@ int ref_obj_load( const char* obj_path, const char* mtl_dir, int64_t* n_faces, i
     return 0;
 }
 
+// Face normal and vertex normals of a loaded face, the statements of example_scenes.cpp:71-81
+// evaluated with the reference's glm.
+void ref_face_normals( int64_t n, const float* pos9, int has_normals, const float* nrm9, float* face3, float* out_nrm9 ) {
+    for ( int64_t i = 0; i < n; i++ ) {
+        vec3 v0 = v3( pos9 + 9 * i ), v1 = v3( pos9 + 9 * i + 3 ), v2 = v3( pos9 + 9 * i + 6 );
+        std::vector<point3> normals;
+        if ( has_normals )
+            for ( int k = 0; k < 3; k++ )
+                normals.push_back( v3( nrm9 + 9 * i + 3 * k ) );
+        vec3 nn;
+        if ( normals.empty() ) {
+            vec3 v2v0 = v2 - v0;
+            vec3 v1v0 = v1 - v0;
+            nn        = normalize( cross( v1v0, v2v0 ) );
+            normals   = { nn, nn, nn };
+        }
+        else { nn = normalize( normals[0] + normals[1] + normals[2] ); }
+        put3( face3 + 3 * i, nn );
+        for ( int k = 0; k < 3; k++ )
+            put3( out_nrm9 + 9 * i + 3 * k, normals[k] );
+    }
+}
+
 } // extern "C"

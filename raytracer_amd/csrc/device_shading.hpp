@@ -470,19 +470,27 @@ MRT_DEV float ibl_pdf_Li( const DShade& s, V3 wi ) { // Light.cpp:317-329, sampl
     float f = s.env_rgb[(size_t)iv * cu + iu];
     return ( f / s.env_marginal_int ) / ( 2 * MRT_PI * MRT_PI * sinTheta );
 }
-// random_dir (sampling.h:199-211): five engine draws
-MRT_DEV V3 random_dir( V3 normal, Pcg32& rng ) {
-    float r1    = pcg_float( rng );
-    float r2    = pcg_float( rng );
+// random_dir (sampling.h:199-211) on its five engine draws u[0..4], in drawing order.
+// vec3( uniform01(engine) - 0.5, ... ): the reference as g++ builds it evaluates the three
+// constructor arguments last to first, so the third draw is z and the fifth x.
+MRT_DEV V3 random_dir_from_draws( V3 normal, const float* u ) {
+    float r1    = u[0];
+    float r2    = u[1];
     float theta = 2.f * MRT_PI * r1;
     float r     = sqrtf( 1.f - r2 );
     V3 local    = mk3( cosf( theta ) * r, sinf( theta ) * r, sqrtf( r2 ) );
-    float rx    = (float)( (double)pcg_float( rng ) - 0.5 );
-    float ry    = (float)( (double)pcg_float( rng ) - 0.5 );
-    float rz    = (float)( (double)pcg_float( rng ) - 0.5 );
+    float rz    = (float)( (double)u[2] - 0.5 );
+    float ry    = (float)( (double)u[3] - 0.5 );
+    float rx    = (float)( (double)u[4] - 0.5 );
     V3 tangent1 = normalize3( cross3( normal, mk3( rx, ry, rz ) ) );
     V3 tangent2 = cross3( tangent1, normal );
     return local.z * normal + local.x * tangent1 + local.y * tangent2;
+}
+MRT_DEV V3 random_dir( V3 normal, Pcg32& rng ) {
+    float u[5];
+    for ( int k = 0; k < 5; k++ )
+        u[k] = pcg_float( rng );
+    return random_dir_from_draws( normal, u );
 }
 
 // ------------------------------------------------------------------ SimpleCamera::get_ray (Camera.cpp:37-67)

@@ -81,6 +81,7 @@ struct mrt_scene {
     DevBuf<float> texels;
     DevBuf<DLight> lights;
     DevBuf<float> light_cdf;
+    std::vector<int32_t> shade_light_kind; // host copy of mrt_light::kind (argument checks)
     DevBuf<float> env_rgb;
     DevBuf<float> env_func_int; // per-row integrals of the Distribution2D (funcInt of each conditional)
     DTrace trace {};

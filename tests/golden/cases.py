@@ -140,3 +140,59 @@ def shape_scene():
     sc.add_plane(Transform().scale(2, 1.5, 1).rotate((1, 0, 0), 30).translate((0, -0.5, 0.2)), m)
     sc.setSimpleCamera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 32, 32, 0.0, 5.0)
     return sc
+
+
+# ---------------------------------------------------------------------------------------- textures,
+# random_dir, CoordinateSystem, UniformLightDistribution (recorded into shading_l2.npz)
+TEXTURE_XF_OPS = [("scale", 0.25, 0.5, 1), ("rotate", 0, 0, 1, 30), ("translate", 0.1, 0.2, 0)]
+TEXTURE_SIZE = (32, 16)  # width, height of the image texture
+CHECKER = ((0.9, 0.8, 0.7), (0.1, 0.2, 0.3))
+
+
+def transform_from_ops(ops):
+    t = Transform()
+    for op in ops:
+        if op[0] == "scale":
+            t.scale(*op[1:4])
+        elif op[0] == "rotate":
+            t.rotate(op[1:4], op[4])
+        else:
+            t.translate(op[1:4])
+    return t
+
+
+def texture_pixels():
+    return np.random.default_rng(77).integers(0, 256, (TEXTURE_SIZE[1], TEXTURE_SIZE[0], 3)).astype(np.uint8)
+
+
+def texture_scene():
+    """Texture 0 = the checker, texture 1 = the image, both under TEXTURE_XF_OPS; materials 0 and 1."""
+    sc = Scene()
+    chk = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, roughness=0.5)
+    sc.set_checker(chk, CHECKER[0], CHECKER[1], transform_from_ops(TEXTURE_XF_OPS))
+    img = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, roughness=0.5)
+    sc.set_image_texture(img, texture_pixels().astype(np.float32) / np.float32(255), transform_from_ops(TEXTURE_XF_OPS))
+    sc.add_plane(Transform(), chk)
+    sc.add_plane(Transform().translate((0, 0, 1)), img)
+    sc.add_sphere(Transform(), chk)
+    sc.setSimpleCamera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 32, 32, 0.0, 5.0)
+    return sc
+
+
+def shading_inputs(n=2048):
+    rng = np.random.default_rng(20240611)
+    g = {"n": n}
+    uv = (rng.random((n, 2), dtype=np.float32) * 6 - 3).astype(np.float32)
+    uv[:64] = np.round(uv[:64] * 2) / 2  # integers and exact halves: the wrap and the checker's <= 0.5 edges
+    g["uv"] = np.ascontiguousarray(uv)
+    g["normal"] = _unit(rng, n)
+    g["seed"] = np.ascontiguousarray(rng.integers(1, 2 ** 31 - 2, n).astype(np.uint32))  # minstd_rand0 seeds
+    g["u1"] = np.ascontiguousarray(rng.random(n, dtype=np.float32))
+    return g
+
+
+# OBJ files whose tinyobj streams are recorded (obj_streams.npz): full arrays for the small ones,
+# SHA-256 digests for the large ones
+OBJ_FILES = ("cornell-box.obj", "bunny.obj", "stanford-bunny.obj", "indoor_plant_02.obj", "veach_mi/plate1.obj",
+             "veach_mi/plate2.obj", "veach_mi/plate3.obj", "veach_mi/plate4.obj", "veach_mi/floor.obj")
+OBJ_FULL_LIMIT = 64  # faces

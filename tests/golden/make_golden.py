@@ -85,6 +85,29 @@ def trees_and_hits():
         json.dump(summary, f, indent=1)
 
 
+def large_trees():
+    """Digests of the reference's kd-trees for the two benchmark scenes (138 902 and 1 111 216
+    triangles).  The reference build of the larger one takes minutes and several GB."""
+    import time
+    summary = {}
+    for name in ("bunny_pair", "million_bunny"):
+        sc = getattr(scenes, name)(64, 36)
+        tree = sc.initKdTree()
+        flat = tree.flatten(0)
+        t0 = time.time()
+        rs = orc.RefScene(flat.desc, orc.xf_ops_for(flat, sc))
+        d = rs.dump()
+        canon = orc.canonical_from_dump(d)
+        summary[name] = {"n_objects": sc.n_objects, "n_nodes": int(len(d["leaf"])), "n_refs": int(len(d["refs"])),
+                         "depth": int(d["depth"]), "digest": orc.tree_digest(canon),
+                         "root_min": d["bmin"][0].view(np.uint32).tolist(), "root_max": d["bmax"][0].view(np.uint32).tolist(),
+                         "reference_build_seconds": round(time.time() - t0, 1)}
+        print("large tree %s: %d nodes, %d refs, depth %d (%.0f s)" % (name, len(d["leaf"]), len(d["refs"]), d["depth"], time.time() - t0))
+        del rs, d, canon
+    with open(os.path.join(HERE, "trees_large.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+
+
 def functions():
     lib = orc.ref()
     g = cases.function_inputs()
@@ -153,6 +176,73 @@ def functions():
     print("functions: %d tables of %d rows" % (len(out), n))
 
 
+def shading_l2():
+    """textures.hpp, random_dir, CoordinateSystem, UniformLightDistribution: the header-only / small
+    pieces of the shading layer that build without Light.h."""
+    lib = orc.ref()
+    g = cases.shading_inputs()
+    n = g["n"]
+    out = {}
+    h = orc.ref_transform_handle(cases.TEXTURE_XF_OPS)
+    a = np.zeros((n, 3), np.float32)
+    lib.ref_checker_value(P(np.asarray(cases.CHECKER[0], np.float32)), P(np.asarray(cases.CHECKER[1], np.float32)), h, n, P(g["uv"]), P(a))
+    out["checker_value"] = a
+    a = np.zeros((n, 3), np.float32)
+    px = np.ascontiguousarray(cases.texture_pixels())
+    if lib.ref_image_value(b"/tmp/_mrt_golden_texture.png", cases.TEXTURE_SIZE[0], cases.TEXTURE_SIZE[1], P(px), h, n, P(g["uv"]), P(a)) != 0:
+        raise SystemExit("could not write the texture PNG")
+    out["image_value"] = a
+    draws, d = np.zeros((n, 5), np.float32), np.zeros((n, 3), np.float32)
+    lib.ref_random_dir(n, P(g["normal"]), P(g["seed"]), P(draws), P(d))
+    out["random_dir_draws"], out["random_dir"] = draws, d
+    a, b = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    lib.ref_coordinate_system(n, P(g["normal"]), P(a), P(b))
+    out["coordinate_system_v2"], out["coordinate_system_v3"] = a, b
+    for nl in cases.LIGHT_COUNTS:
+        off, pdf = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        lib.ref_uniform_light_distribution(nl, n, P(g["u1"]), P(off), P(pdf))
+        out["uniform_light_off_%d" % nl], out["uniform_light_pdf_%d" % nl] = off, pdf
+    np.savez_compressed(os.path.join(HERE, "shading_l2.npz"), **{k: (v.view(np.uint32) if v.dtype == np.float32 else v) for k, v in out.items()})
+    print("shading_l2: %d tables of %d rows" % (len(out), n))
+
+
+def ref_obj_streams(path):
+    """tinyobj::LoadObj as scene.cpp:179-187 calls it + the face walk of example_scenes.cpp:32-81."""
+    lib = orc.ref()
+    nf, nm, hn, ht = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+    mdir = (os.path.dirname(path) + "/").encode()
+    if lib.ref_obj_load(path.encode(), mdir, C.byref(nf), C.byref(nm), C.byref(hn), C.byref(ht), None, None, None, None, None) != 0:
+        raise SystemExit("tinyobj could not load " + path)
+    n = nf.value
+    pos, nrm, tex = np.zeros((n, 9), np.float32), np.zeros((n, 9), np.float32), np.zeros((n, 6), np.float32)
+    mid, mtl = np.zeros(n, np.int32), np.zeros((max(nm.value, 1), 10), np.float32)
+    lib.ref_obj_load(path.encode(), mdir, C.byref(nf), C.byref(nm), C.byref(hn), C.byref(ht), P(pos), P(nrm), P(tex), P(mid), P(mtl))
+    face, vn = np.zeros((n, 3), np.float32), np.zeros((n, 9), np.float32)
+    lib.ref_face_normals(n, P(pos), hn.value, P(nrm), P(face), P(vn))
+    return {"pos": pos, "vertex_normals": vn, "face_normal": face, "tex": tex, "material_id": mid, "mtl": mtl[:nm.value],
+            "has_normals": hn.value, "has_texcoords": ht.value}
+
+
+def obj_streams():
+    arrays, summary = {}, {}
+    for name in cases.OBJ_FILES:
+        s = ref_obj_streams(scenes.asset(name))
+        key = name.replace("/", "_").replace(".obj", "").replace("-", "_")
+        n = len(s["pos"])
+        summary[name] = {"key": key, "faces": n, "materials": int(len(s["mtl"])), "has_normals": s["has_normals"],
+                         "has_texcoords": s["has_texcoords"],
+                         "digest": {k: cases.digest(s[k]) for k in ("pos", "vertex_normals", "tex", "material_id")}}
+        arrays[key + "_mtl"] = s["mtl"].view(np.uint32)
+        if n <= cases.OBJ_FULL_LIMIT:
+            for k in ("pos", "vertex_normals", "face_normal", "tex"):
+                arrays[key + "_" + k] = s[k].view(np.uint32)
+            arrays[key + "_material_id"] = s["material_id"]
+        print("obj %s: %d faces, %d MTL materials" % (name, n, len(s["mtl"])))
+    np.savez_compressed(os.path.join(HERE, "obj_streams.npz"), **arrays)
+    with open(os.path.join(HERE, "obj_streams.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+
+
 if __name__ == "__main__":
     if not orc.have_ref():
         raise SystemExit("oracle/_ref/libmrt_ref.so is missing: run `make -C oracle ref` in the build container")
@@ -160,3 +250,7 @@ if __name__ == "__main__":
     transforms()
     trees_and_hits()
     functions()
+    shading_l2()
+    obj_streams()
+    if "--large-trees" in sys.argv:
+        large_trees()

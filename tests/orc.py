@@ -60,6 +60,11 @@ def oracle():
         lib.orc_camera.argtypes = [vp, vp, vp] + [C.c_float] * 5 + [C.POINTER(abi.Camera)]
         lib.orc_camera_rays.argtypes = [C.POINTER(abi.Camera), C.c_int64] + [vp] * 4
         lib.orc_sample_streams.argtypes = [C.c_uint32] * 5 + [vp] * 3
+        lib.orc_texture_value.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, C.c_int64, vp, vp]
+        lib.orc_random_dir_replay.argtypes = [C.c_int64, vp, vp, vp]
+        lib.orc_coordinate_system.argtypes = [C.c_int64, vp, vp, vp]
+        lib.orc_uniform_light_distribution.argtypes = [C.c_int, C.c_int64, vp, vp, vp]
+        lib.orc_face_normals.argtypes = [C.c_int64, vp, C.c_int, vp, vp, vp]
         lib.orc_render.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.RenderParams), C.c_int, vp, vp,
                                    C.POINTER(abi.RenderStats), C.POINTER(abi.TraceStats), vp, C.c_int]
         _orc = lib
@@ -113,6 +118,14 @@ def ref():
         lib.ref_camera_new.argtypes = [vp, vp, vp] + [C.c_float] * 5
         lib.ref_camera_rays.argtypes = [vp, C.c_int64] + [vp] * 4
         lib.ref_camera_params.argtypes = [vp, vp]
+        lib.ref_checker_value.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+        lib.ref_image_value.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, C.c_int64, vp, vp]
+        lib.ref_random_dir.argtypes = [C.c_int64, vp, vp, vp, vp]
+        lib.ref_coordinate_system.argtypes = [C.c_int64, vp, vp, vp]
+        lib.ref_uniform_light_distribution.argtypes = [C.c_int, C.c_int64, vp, vp, vp]
+        lib.ref_obj_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32), vp, vp, vp, vp, vp]
+        lib.ref_face_normals.argtypes = [C.c_int64, vp, C.c_int, vp, vp, vp]
         _ref = lib
     return _ref
 

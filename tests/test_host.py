@@ -294,3 +294,62 @@ def test_intersect_and_render_reject_null_arguments(built):
     assert lib.mrt_intersect(None, 0, None, None, 0, 0, None, None) == 1
     assert lib.mrt_render(None, None, None, 0, None, None) == 1
     assert b"NULL" in lib.mrt_last_error()
+
+
+# ---------------------------------------------------------------------------------------- ingestion pinned
+@pytest.mark.parametrize("name", cases.OBJ_FILES)
+def test_obj_loader_matches_tinyobj_streams(built, name):
+    """addObjectsFromFile of the host library against the per-face streams recorded from the
+    reference's tiny_obj_loader.h + the face walk of example_scenes.cpp:32-81: positions, vertex
+    normals (from the file, or the face normal when it has none), texture coordinates, and the
+    per-face materials made from the MTL entries -- bit for bit, quads fanned as tinyobj fans them
+    (primitive ids depend on the order)."""
+    summary = json.load(open(os.path.join(GOLD, "obj_streams.json")))[name]
+    z = np.load(os.path.join(GOLD, "obj_streams.npz"))
+    key = summary["key"]
+    sc = Scene()
+    default = sc.CreateMaterial()
+    n = sc.addObjectsFromFile(scenes.asset(name), default, Transform())
+    assert n == summary["faces"]
+    sc.setSimpleCamera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 32, 32, 0.0, 5.0)
+    flat = sc.initKdTree().flatten(0)  # keeps the arrays behind the description alive
+    d = flat.desc.contents
+    assert d.n_objects == n
+    got = {"pos": np.ctypeslib.as_array(d.tri_p, shape=(n, 9)), "vertex_normals": np.ctypeslib.as_array(d.tri_n, shape=(n, 9)),
+           "tex": np.ctypeslib.as_array(d.tri_uv, shape=(n, 6))}
+    for k, a in got.items():
+        assert cases.digest(np.ascontiguousarray(a, np.float32)) == summary["digest"][k], k
+        if n <= cases.OBJ_FULL_LIMIT:
+            assert np.array_equal(bits(a).reshape(n, -1), z["%s_%s" % (key, k)])
+    om = np.ctypeslib.as_array(d.obj_material, shape=(n,))
+    mtl = z[key + "_mtl"].view(np.float32).reshape(-1, 10)
+    assert len(mtl) == summary["materials"]
+    if len(mtl) == 0:
+        assert (om == default).all()  # no MTL: every face gets the default material
+        return
+    # one new Material per face, in face order, after the default one (example_scenes.cpp:83-92)
+    assert np.array_equal(om, default + 1 + np.arange(n))
+    if n <= cases.OBJ_FULL_LIMIT:
+        mid = z[key + "_material_id"]
+        for f in range(n):
+            m, want = d.materials[int(om[f])], mtl[mid[f]]
+            assert (m.ior, tuple(m.albedo), tuple(m.emission)) == (want[0], tuple(want[1:4]), tuple(want[4:7]))
+            mirror = tuple(want[7:10]) == (1.0, 1.0, 1.0)  # example_scenes.cpp:112-116
+            assert m.type == (abi.MRT_MAT_SPECULAR if mirror else abi.MRT_MAT_DIFFUSE)
+            assert (m.roughness, m.metalness) == ((np.float32(0.002), 1.0) if mirror else (1.0, 0.0))
+        assert d.n_lights == int((mtl[mid][:, 4:7] != 0).any(axis=1).sum())
+
+
+@pytest.mark.parametrize("name", ("bunny_pair", "million_bunny"))
+def test_benchmark_scene_trees_identical_to_reference(built, name):
+    """The kd-trees of the two benchmark scenes (138 902 and 1 111 216 triangles) built by the host
+    library against the digests recorded from the reference's initKdTree."""
+    summary = json.load(open(os.path.join(GOLD, "trees_large.json")))[name]
+    sc = getattr(scenes, name)(64, 36)
+    assert sc.n_objects == summary["n_objects"]
+    tree = sc.initKdTree()
+    assert tree.counts() == (summary["n_nodes"], summary["n_refs"], summary["depth"])
+    assert orc.tree_digest(orc.canonical_from_dump(tree.dump())) == summary["digest"]
+    flat = tree.flatten(1)
+    d = flat.desc.contents
+    assert bits(np.array(d.root_min)).tolist() == summary["root_min"] and bits(np.array(d.root_max)).tolist() == summary["root_max"]

@@ -260,3 +260,54 @@ def test_live_reference_large_mesh(built):
         assert np.array_equal(bits(a["t"])[h], bits(b["t"])[h])
         if not shadow:
             assert np.array_equal(a["prim"][h], b["prim"][h])
+
+
+# ------------------------------------------------------------------------------------------ shading layer,
+# the pieces that build without Light.h: textures.hpp, random_dir, CoordinateSystem, LightDistribution.cpp
+@pytest.fixture(scope="module")
+def l2():
+    return np.load(os.path.join(GOLD, "shading_l2.npz")), cases.shading_inputs()
+
+
+def test_textures_match_reference(built, l2):
+    """texture::value(u, v, duv) of a checker_texture and an image_texture (read back through the
+    reference's loadPng) under a texture transform: arithmetic + table lookup, bit-exact."""
+    z, g = l2
+    lib = orc.oracle()
+    flat = cases.texture_scene().initKdTree().flatten(0)
+    n = g["n"]
+    for tex, key in ((0, "checker_value"), (1, "image_value")):
+        out = np.zeros((n, 3), np.float32)
+        lib.orc_texture_value(flat.desc, tex, n, P(g["uv"]), P(out))
+        assert np.array_equal(bits(out), z[key]), key
+    # both colours of the checker and many texels are exercised
+    assert len(np.unique(z["checker_value"][:, 0])) == 2 and len(np.unique(z["image_value"], axis=0)) > 200
+
+
+def test_random_dir_matches_reference(built, l2):
+    """random_dir fed with the engine draws recorded from the reference's own thread-local engine,
+    in drawing order: pins the arithmetic and which draw feeds which component (g++ evaluates the
+    vec3 constructor arguments last to first)."""
+    z, g = l2
+    n = g["n"]
+    out = np.zeros((n, 3), np.float32)
+    draws = np.ascontiguousarray(gold_f(z, "random_dir_draws"))
+    orc.oracle().orc_random_dir_replay(n, P(g["normal"]), P(draws), P(out))
+    close(out, gold_f(z, "random_dir"), rel=2e-6, abs_=1e-7)  # sin / cos / sqrt of glibc
+    assert (bits(out) == z["random_dir"]).all(axis=1).mean() > 0.99
+    # cosine-weighted about the normal
+    assert (np.sum(out * g["normal"], axis=1) > -1e-6).all()
+
+
+def test_coordinate_system_and_light_distribution_match_reference(built, l2):
+    z, g = l2
+    lib = orc.oracle()
+    n = g["n"]
+    a, b = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    lib.orc_coordinate_system(n, P(g["normal"]), P(a), P(b))
+    assert np.array_equal(bits(a), z["coordinate_system_v2"]) and np.array_equal(bits(b), z["coordinate_system_v3"])
+    for nl in cases.LIGHT_COUNTS:
+        off, pdf = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        lib.orc_uniform_light_distribution(nl, n, P(g["u1"]), P(off), P(pdf))
+        assert np.array_equal(off, z["uniform_light_off_%d" % nl]) and np.array_equal(bits(pdf), z["uniform_light_pdf_%d" % nl])
+        assert off.min() == 0 and off.max() == nl - 1
