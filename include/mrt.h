@@ -14,8 +14,11 @@
  *   - all arrays in mrt_scene_desc are HOST memory, read during mrt_scene_create and not
  *     retained (the library keeps its own device copy in its own layout);
  *   - ray / hit / image buffers may be host or device memory, selected by MRT_BUF_DEVICE;
- *   - one mrt_scene belongs to one HIP device; calls on one handle must be serialised by the
- *     caller, calls on different handles may run concurrently;
+ *   - one mrt_scene belongs to one HIP device; calls on one handle must be made one after another
+ *     (not from two threads at once); the device work of successive calls on one handle is
+ *     executed in call order even when the calls name different streams (the handle's scratch is
+ *     shared, so the library orders them with an event); calls on different handles may run
+ *     concurrently;
  *   - all arithmetic is IEEE fp32, unfused, in the reference's evaluation order, so that hit
  *     primitive ids are bit-identical to the reference's intersectKdTree.
  */
@@ -278,6 +281,22 @@ mrt_status mrt_resolve( mrt_scene* scene,
                         float* rgb_out,
                         uint32_t placement,
                         void* stream );
+
+/* Several GPUs of one node driven from ONE process (the reference renders in one process; nothing
+ * in it corresponds to these two calls -- they are what its CPURenderer::run would call in place of
+ * its OpenMP loop over scanlines, CPURenderer.cpp:40-44, when the node has more than one GPU).
+ *
+ * mrt_reduce: images[i] is a device-resident [n_floats] radiance-sum image on the device of
+ * scenes[i]; all of them are added, in handle order, onto images[root] (peer copies over xGMI +
+ * one add per source).  Waits for all work on the devices involved before and after.
+ *
+ * mrt_render_multi: mrt_render of one frame with the sample range [sample_begin, sample_end) of
+ * `params` divided among the n handles (one per device, each created from the same description),
+ * rendered side by side, reduced onto handle 0 and ADDED to the host image rgb_sum_host.  Sampling
+ * is keyed by (seed, pixel, sample index), so the frame equals the single-handle frame up to the
+ * order of the fp32 additions of the per-handle sums. */
+mrt_status mrt_reduce( mrt_scene* const* scenes, float* const* images, int32_t n, uint64_t n_floats, int32_t root );
+mrt_status mrt_render_multi( mrt_scene* const* scenes, int32_t n, const mrt_render_params* params, float* rgb_sum_host, mrt_render_stats* stats );
 
 /* Diagnostics: evaluates ONE device function of the shading code on `n` rows of host floats
  * (row strides in floats), so that each function can be compared with a CPU implementation in

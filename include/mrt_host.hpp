@@ -219,8 +219,9 @@ class KdTree
     KdTreeNode* root = nullptr;
     std::vector<int> outOfTree;
     std::vector<int> inTree;
-    mrt_scene* device_scene = nullptr; // created on first intersectKdTree / by HIPRenderer
-    struct FlatScene* flat  = nullptr;
+    mrt_scene* device_scene = nullptr; // created on first intersectKdTree / by Pathtracer::preprocess; freed with the tree
+    int device_of_scene     = -1;      // the device device_scene lives on
+    struct FlatScene* flat  = nullptr; // likewise
 };
 KdTree* initKdTree( Scene* scene );                 // kdtree.cpp:54-158, multi-threaded, same tree
 KdTree* initKdTree( Scene* scene, int n_threads );
@@ -266,6 +267,62 @@ struct FlatScene {
 enum NodeLayout { LAYOUT_PREORDER_PAIRS = 0, LAYOUT_BFS_TOP = 1 };
 FlatScene* flatten( Scene* scene, KdTree* tree, NodeLayout layout = LAYOUT_BFS_TOP );
 
+// Sampler configuration (sampling/sampler.h:30-75, sampling/stratified.h).  The sample values are
+// generated on the GPU from (seed, pixel, sample index, dimension); the host object carries what
+// CPURenderer::init puts into its sampler: the stratification grid and the number of
+// pre-stratified dimensions.
+class Sampler
+{
+  public:
+    explicit Sampler( int64_t samplesPerPixel ) : samplesPerPixel( samplesPerPixel ) {}
+    virtual ~Sampler() = default;
+    const int64_t samplesPerPixel;
+};
+class StratifiedSampler : public Sampler
+{
+  public:
+    StratifiedSampler( int xPixelSamples, int yPixelSamples, bool jitterSamples, int nSampledDimensions ) :
+        Sampler( (int64_t)xPixelSamples * yPixelSamples ), xPixelSamples( xPixelSamples ), yPixelSamples( yPixelSamples ),
+        jitterSamples( jitterSamples ), nSampledDimensions( nSampledDimensions ) {}
+    const int xPixelSamples, yPixelSamples;
+    const bool jitterSamples;
+    const int nSampledDimensions;
+};
+
+// Camera samples an integrator is asked to trace: sample indices [sample_begin, sample_end) of every
+// pixel of scanlines [row_begin, row_end) of a width x height image.
+struct SampleRange {
+    uint32_t width = 0, height = 0, sample_begin = 0, sample_end = 0, row_begin = 0, row_end = 0, seed = 1;
+};
+
+// Integrator / Pathtracer (integrator.h:25-43).  preprocess() is where the reference builds its
+// UniformLightDistribution (integrator.cpp:124-126); here it also uploads scene and tree to the
+// devices.  The per-ray trace_ray(Scene*, Ray&, KdTree*, Intersection*, Sampler*) cannot cross to
+// a GPU one call at a time: trace_samples is its batched form -- the camera samples of `range`,
+// traced to completion, their radiance ADDED per pixel to rgb_sum ([height][width][3], host).
+class Integrator
+{
+  public:
+    virtual ~Integrator() = default;
+    virtual void preprocess( Scene* scene, KdTree* tree, Sampler* sampler, const std::vector<int>& devices ) = 0;
+    virtual void trace_samples( const SampleRange& range, float* rgb_sum, mrt_render_stats* stats ) = 0;
+};
+class Pathtracer : public Integrator
+{
+  public:
+    Pathtracer( int maxDepth, Sampler* sampler ) : m_maxDepth( maxDepth ), m_sampler( sampler ) {}
+    ~Pathtracer() override;
+    void preprocess( Scene* scene, KdTree* tree, Sampler* sampler, const std::vector<int>& devices ) override;
+    void trace_samples( const SampleRange& range, float* rgb_sum, mrt_render_stats* stats ) override;
+    int m_maxDepth;
+
+  private:
+    Sampler* m_sampler;
+    KdTree* m_tree = nullptr;
+    std::vector<mrt_scene*> m_devices; // one handle per device; [0] is the tree's own
+    std::vector<mrt_scene*> m_owned;   // the handles this integrator created itself
+};
+
 // rendering/ImageRenderer.h:5-17
 class ImageRenderer
 {
@@ -287,7 +344,11 @@ class HIPRenderer : public ImageRenderer
 {
   public:
     int spp_x = 32, spp_y = 32, maxDepth = 5, device = 0;
+    // more than one entry: the samples of every Render call are divided among these devices
+    // (mrt_render_multi); empty = { device }
+    std::vector<int> devices;
     uint32_t seed = 1;
+    ~HIPRenderer() override { destroy(); }
     void init( std::string& imageName, vec2 resolution, Scene* scene ) override;
     void destroy() override;
     void run() override; // the whole spp_x * spp_y grid in one go
@@ -309,7 +370,9 @@ class HIPRenderer : public ImageRenderer
     bool loadCheckpoint( const char* filename );
 
   private:
-    KdTree* m_kdTree = nullptr;
+    KdTree* m_kdTree         = nullptr;
+    Sampler* m_sampler       = nullptr; // CPURenderer.cpp:15
+    Integrator* m_integrator = nullptr; // CPURenderer.cpp:18
     uint32_t m_w = 0, m_h = 0;
     uint32_t m_next = 0; // first sample index not rendered yet
     std::vector<float> m_sum, m_image;

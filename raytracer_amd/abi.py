@@ -125,6 +125,10 @@ def hip():
         lib.mrt_render.restype = C.c_int32
         lib.mrt_resolve.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.mrt_resolve.restype = C.c_int32
+        lib.mrt_reduce.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.c_int32]
+        lib.mrt_reduce.restype = C.c_int32
+        lib.mrt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
+        lib.mrt_render_multi.restype = C.c_int32
         lib.mrt_debug_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32]
         lib.mrt_debug_eval.restype = C.c_int32
         _hip = lib
@@ -179,6 +183,8 @@ def host():
             "mrth_intersect_kdtree": (ci, [vp, vp, f32p, f32p, C.c_float, C.c_float, ci, f32p]),
             "mrth_hip_render": (ci, [vp, C.c_uint32, C.c_uint32, ci, ci, ci, C.c_uint32, ci, f32p,
                                      C.POINTER(RenderStats), C.POINTER(C.c_double)]),
+            "mrth_hip_render_devices": (ci, [vp, C.c_uint32, C.c_uint32, ci, ci, ci, C.c_uint32, C.POINTER(C.c_int), ci, f32p,
+                                             C.POINTER(RenderStats), C.POINTER(C.c_double)]),
             "mrth_hip_render_progressive": (ci, [vp, C.c_uint32, C.c_uint32, ci, ci, ci, C.c_uint32, ci, C.c_uint32, ci,
                                                  C.c_char_p, f32p, C.POINTER(RenderStats)]),
         }

@@ -320,13 +320,19 @@ int mrth_intersect_kdtree( void* scene, void* tree, const float* o3, const float
 
 // HIPRenderer::init + run + destroy; rgb_sum receives the linear radiance sums.
 int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, float* rgb_sum, mrt_render_stats* stats, double* seconds ) {
+    return mrth_hip_render_devices( scene, w, h, spp_x, spp_y, max_depth, seed, &device, 1, rgb_sum, stats, seconds );
+}
+
+int mrth_hip_render_devices( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, const int* devices, int n_devices, float* rgb_sum, mrt_render_stats* stats, double* seconds ) {
     return guarded( [&] {
+        if ( !devices || n_devices < 1 ) throw std::invalid_argument( "no device" );
         HIPRenderer r;
         r.spp_x    = spp_x;
         r.spp_y    = spp_y;
         r.maxDepth = max_depth;
         r.seed     = seed;
-        r.device   = device;
+        r.device   = devices[0];
+        r.devices.assign( devices, devices + n_devices );
         std::string name;
         r.init( name, vec2 { (float)w, (float)h }, static_cast<Scene*>( scene ) );
         r.run();

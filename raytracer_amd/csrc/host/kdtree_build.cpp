@@ -27,6 +27,8 @@ KdTreeNode::~KdTreeNode() {
 }
 KdTree::~KdTree() {
     delete root;
+    if ( device_scene ) mrt_scene_destroy( device_scene ); // created lazily by intersectKdTree / Pathtracer::preprocess
+    delete flat;
 }
 
 namespace {

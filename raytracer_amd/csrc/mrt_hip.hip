@@ -16,6 +16,7 @@
 #include <mutex>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
@@ -87,6 +88,10 @@ struct mrt_scene {
     DTrace trace {};
     DShade shade {};
     RenderWorkspace ws;
+    // Calls on one handle share its scratch (d_stats, the render workspace).  Every call that uses
+    // it waits on `order` when it starts and records it when it has queued its work, so calls made
+    // one after another on DIFFERENT streams are still executed in call order.
+    hipEvent_t order = nullptr;
     uint64_t* d_stats = nullptr; // mrt_intersect: 8 x u64 traversal counters, then the MRT_DEAL_WORDS chunk counters
     uint32_t tree_depth = 0;
     int n_cus           = 256;
@@ -110,7 +115,9 @@ mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out ) {
     while ( !stack.empty() ) {
         auto [node, depth] = stack.back();
         stack.pop_back();
-        visited++;
+        // a tree visits every node once: more visits than nodes means a node with two parents
+        // (checked here, so that a malformed description cannot make this walk exponential)
+        if ( ++visited > d->n_nodes ) return fail( MRT_ERR_INVALID, "tree visits more nodes than it has" );
         if ( depth > *depth_out ) *depth_out = depth;
         const mrt_kdnode& n = d->nodes[node];
         if ( ( n.w1 & 3u ) == 3u ) {
@@ -128,7 +135,6 @@ mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out ) {
         stack.emplace_back( left, depth + 1 );
         stack.emplace_back( left + 1, depth + 1 );
     }
-    if ( visited > d->n_nodes ) return fail( MRT_ERR_INVALID, "tree visits more nodes than it has" );
     if ( *depth_out + 2 > MRT_STACK_MAX ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree deeper than the traversal stack (" + std::to_string( *depth_out ) + ")" );
     return MRT_OK;
 }
@@ -166,6 +172,8 @@ mrt_status build_tree_records( const mrt_scene_desc* d, std::vector<uint4>& node
             }
             else out[1] = ( w1 & 3u ) | ( record[w1 >> 2] << 2 ); // its children are adjacent nodes of even depth: adjacent records
         };
+        // the kernels form a record's byte offset (record << 5) in 32 bits
+        if ( n_records >= ( 1u << 27 ) ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree too large (limit: 2^27 nodes of even depth)" );
         nodes.assign( 2 * (size_t)n_records, make_uint4( 0, 0, 0, 0 ) );
         for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
             if ( level[i] != 0 ) continue;
@@ -194,6 +202,7 @@ mrt_status scratch_for_device( int device, uint32_t** out ); // with mrt_interse
 }
 mrt_scene::~mrt_scene() {
     if ( d_stats ) (void)hipFree( d_stats );
+    if ( order ) (void)hipEventDestroy( order );
     free_workspace( ws );
 }
 
@@ -225,6 +234,10 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         if ( std::memcmp( t0.m, ident, 36 ) || std::memcmp( t0.inv, ident, 36 ) || std::memcmp( t0.t, zero, 12 ) )
             return fail( MRT_ERR_INVALID, "transform 0 must be the identity" );
     }
+    if ( d->n_out_of_tree && !d->out_of_tree ) return fail( MRT_ERR_INVALID, "out_of_tree is NULL" );
+    if ( d->n_textures && !d->textures ) return fail( MRT_ERR_INVALID, "textures is NULL" );
+    if ( d->n_texels && !d->texels ) return fail( MRT_ERR_INVALID, "texels is NULL" );
+    if ( d->n_lights && !d->lights ) return fail( MRT_ERR_INVALID, "lights is NULL" );
     uint32_t depth = 0;
     mrt_status vs  = validate_tree( d, &depth );
     if ( vs != MRT_OK ) return vs;
@@ -296,6 +309,8 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     HIP_TRY( s->xforms.upload( xforms ) );
     HIP_TRY( s->out_of_tree.upload( std::vector<uint32_t>( d->out_of_tree, d->out_of_tree + d->n_out_of_tree ) ) );
     HIP_TRY( hipMalloc( (void**)&s->d_stats, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ) ) );
+    HIP_TRY( hipEventCreateWithFlags( &s->order, hipEventDisableTiming ) );
+    HIP_TRY( hipEventRecord( s->order, 0 ) );
 
     DTrace& t     = s->trace;
     t.nodes       = s->nodes.p;
@@ -411,6 +426,7 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
         du    = hits->u;
         dv    = hits->v;
     }
+    HIP_TRY( hipStreamWaitEvent( stream, sc->order, 0 ) );
     HIP_TRY( hipMemsetAsync( sc->d_stats, 0, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ), stream ) );
     const dim3 block( MRT_TRACE_BLOCK );
     unsigned long long* ds = (unsigned long long*)sc->d_stats;
@@ -427,6 +443,7 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
     }
 #undef LAUNCH
     HIP_TRY( hipGetLastError() );
+    if ( !stats ) HIP_TRY( hipEventRecord( sc->order, stream ) ); // with stats the call waits for the stream below
     if ( placement == MRT_BUF_HOST ) {
         HIP_TRY( hipMemcpyAsync( hits->prim, dprim, n * sizeof( int32_t ), hipMemcpyDeviceToHost, stream ) );
         HIP_TRY( hipMemcpyAsync( hits->t, dt, n * sizeof( float ), hipMemcpyDeviceToHost, stream ) );
@@ -436,6 +453,7 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
     if ( stats ) {
         uint64_t h[8];
         HIP_TRY( hipMemcpyAsync( h, sc->d_stats, sizeof( h ), hipMemcpyDeviceToHost, stream ) );
+        HIP_TRY( hipEventRecord( sc->order, stream ) );
         HIP_TRY( hipStreamSynchronize( stream ) );
         stats->inner      = h[0];
         stats->leaves     = h[1];

@@ -160,12 +160,15 @@ class Scene:
     def initKdTree(self, n_threads=0):
         return KdTree(self, n_threads)
 
-    def hip_render(self, width, height, spp_x, spp_y, max_depth=5, seed=1, device=0):
+    def hip_render(self, width, height, spp_x, spp_y, max_depth=5, seed=1, device=0, devices=None):
         """HIPRenderer::init + run + destroy (the GPU sibling of CPURenderer).  Returns the linear
-        radiance sums [h][w][3], the render statistics and the seconds run() took."""
+        radiance sums [h][w][3], the render statistics and the seconds run() took.  `devices`: a list
+        of device indices among which the samples are divided (HIPRenderer::devices)."""
         img = np.zeros((height, width, 3), np.float32)
         st, sec = abi.RenderStats(), C.c_double()
-        r = abi.host().mrth_hip_render(self._h, width, height, spp_x, spp_y, max_depth, seed, device, _fp(img), C.byref(st), C.byref(sec))
+        devs = (C.c_int * len(devices))(*devices) if devices else (C.c_int * 1)(device)
+        r = abi.host().mrth_hip_render_devices(self._h, width, height, spp_x, spp_y, max_depth, seed, devs, len(devs), _fp(img),
+                                               C.byref(st), C.byref(sec))
         if r < 0:
             raise MrtError(abi.host().mrth_last_error().decode())
         return img, st, sec.value

@@ -448,3 +448,37 @@ def test_scene_without_a_tree():
     dev.close()
     gpu, cpu, rs, crs = render_both(sc, 48, 48, 2, 2, 4, 17)
     check_images(gpu, cpu, 4)
+
+
+def test_multi_device_reduce_and_split_render():
+    """mrt_reduce and mrt_render_multi / HIPRenderer::devices, rehearsed with several handles on the
+    one GPU of the box: the frame whose samples are divided among two handles, reduced on the
+    device, equals the single-handle frame up to the order of the fp32 additions."""
+    import ctypes as C
+    import torch
+    sc = scenes.small_bunny(48, 48, env_pixels=scenes.synthetic_env())
+    one, st1, _ = sc.hip_render(48, 48, 4, 4, max_depth=4, seed=11)
+    two, st2, _ = sc.hip_render(48, 48, 4, 4, max_depth=4, seed=11, devices=[0, 0])
+    three, st3, _ = sc.hip_render(48, 48, 4, 4, max_depth=4, seed=11, devices=[0, 0, 0])
+    assert np.allclose(two, one, rtol=2e-6, atol=1e-6) and np.allclose(three, one, rtol=2e-6, atol=1e-6)
+    for st in (st2, st3):
+        assert (st.paths, st.rays_closest, st.rays_any) == (st1.paths, st1.rays_closest, st1.rays_any)
+    # more handles than samples: the surplus handles render nothing
+    few, stf, _ = sc.hip_render(48, 48, 1, 2, max_depth=2, seed=3, devices=[0, 0, 0])
+    ref, _, _ = sc.hip_render(48, 48, 1, 2, max_depth=2, seed=3)
+    assert np.allclose(few, ref, rtol=2e-6, atol=1e-6) and stf.paths == 48 * 48 * 2
+
+    # mrt_reduce on its own: images added onto the root in handle order
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    rng = np.random.default_rng(2)
+    host = [rng.random(1000, dtype=np.float32) for _ in range(3)]
+    imgs = [torch.from_numpy(h).cuda() for h in host]
+    torch.cuda.synchronize()
+    handles = (C.c_void_p * 3)(dev._h, dev._h, dev._h)
+    ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in imgs])
+    assert abi.hip().mrt_reduce(handles, ptrs, 3, 1000, 1) == abi.MRT_OK
+    assert np.array_equal(imgs[1].cpu().numpy(), (host[1] + host[0]) + host[2])
+    assert np.array_equal(imgs[0].cpu().numpy(), host[0]) and np.array_equal(imgs[2].cpu().numpy(), host[2])
+    assert abi.hip().mrt_reduce(handles, ptrs, 3, 1000, 3) != abi.MRT_OK  # root out of range
+    dev.close()
