@@ -30,6 +30,8 @@
 #include "shapes/triangle.h"
 #include "textures.hpp"
 
+#include "flatten_ref.h" // integration/: the reference-side adapter under test
+
 #include <lodepng.h>
 
 #include <cstdint>
@@ -687,6 +689,38 @@ void ref_face_normals( int64_t n, const float* pos9, int has_normals, const floa
         for ( int k = 0; k < 3; k++ )
             put3( out_nrm9 + 9 * i + 3 * k, normals[k] );
     }
+}
+
+// ---------------------------------------------------------------- integration/flatten_ref.cpp
+// The reference-side adapter run on a reference Scene + KdTree; returns the description it made
+// (owned by the returned handle).
+void* ref_adapter_flatten( void* scene, void* tree ) {
+    auto* f = new MrtFlat;
+    try {
+        mrtFlattenGeometry( static_cast<Scene*>( scene ), static_cast<KdTree*>( tree ), *f );
+    }
+    catch ( const std::exception& ) {
+        delete f;
+        return nullptr;
+    }
+    return f;
+}
+const mrt_scene_desc* ref_adapter_desc( void* flat ) {
+    return &static_cast<MrtFlat*>( flat )->desc;
+}
+void ref_adapter_free( void* flat ) {
+    delete static_cast<MrtFlat*>( flat );
+}
+void ref_scene_set_camera( void* scene, void* cam ) {
+    static_cast<Scene*>( scene )->cam = static_cast<Camera*>( cam );
+}
+// A checker_texture of two solid colours on material `mat` of the scene (Material::m_texture)
+void ref_material_set_checker( void* scene_, int mat, const float* even3, const float* odd3, void* xf ) {
+    auto* scene     = static_cast<Scene*>( scene_ );
+    auto* tex       = new checker_texture( color3( even3[0], even3[1], even3[2] ), color3( odd3[0], odd3[1], odd3[2] ) );
+    if ( xf ) tex->m_transform = *static_cast<Transform*>( xf );
+    scene->m_Materials[mat].m_texture  = tex;
+    scene->m_Materials[mat].m_MatModel = MaterialModel::COOK_TORRANCE;
 }
 
 } // extern "C"

@@ -125,6 +125,13 @@ def ref():
         lib.ref_uniform_light_distribution.argtypes = [C.c_int, C.c_int64, vp, vp, vp]
         lib.ref_obj_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), vp, vp, vp, vp, vp]
+        lib.ref_adapter_flatten.restype = vp
+        lib.ref_adapter_flatten.argtypes = [vp, vp]
+        lib.ref_adapter_desc.restype = C.POINTER(abi.SceneDesc)
+        lib.ref_adapter_desc.argtypes = [vp]
+        lib.ref_adapter_free.argtypes = [vp]
+        lib.ref_scene_set_camera.argtypes = [vp, vp]
+        lib.ref_material_set_checker.argtypes = [vp, C.c_int, vp, vp, vp]
         lib.ref_face_normals.argtypes = [C.c_int64, vp, C.c_int, vp, vp, vp]
         _ref = lib
     return _ref

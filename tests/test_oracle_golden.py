@@ -311,3 +311,56 @@ def test_coordinate_system_and_light_distribution_match_reference(built, l2):
         lib.orc_uniform_light_distribution(nl, n, P(g["u1"]), P(off), P(pdf))
         assert np.array_equal(off, z["uniform_light_off_%d" % nl]) and np.array_equal(bits(pdf), z["uniform_light_pdf_%d" % nl])
         assert off.min() == 0 and off.max() == nl - 1
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("name", cases.SCENES)
+def test_reference_side_adapter_flattens_like_the_product(built, name):
+    """integration/flatten_ref.cpp (the adapter a maintainer drops into the reference tree) run on
+    the reference's own Scene + KdTree gives, table for table, the description the product's
+    flatten() makes of the same scene: objects, transforms, kd-tree nodes, references, root box,
+    out-of-tree list, camera.  Container only: the adapter is compiled against the reference's headers."""
+    lib = orc.ref()
+    sc, w, h = cases.make_scene(name)
+    tree = sc.initKdTree()
+    flat = tree.flatten(0)  # pre-order with adjacent children: the adapter's node order
+    d = flat.desc.contents
+    rs = orc.RefScene(flat.desc, orc.xf_ops_for(flat, sc))
+    cam = {"cornell": cases.CAMERA_CASES["scene9"][:3] + (60.0, 64.0, 64.0, 0.001, 8.1)}.get(name)
+    if cam:
+        frm, at, up = [np.asarray(x, np.float32) for x in cam[:3]]
+        lib.ref_scene_set_camera(rs.scene, lib.ref_camera_new(P(frm), P(at), P(up), *[float(x) for x in cam[3:]]))
+    h_ = lib.ref_adapter_flatten(rs.scene, rs.tree)
+    assert h_, "the adapter refused the scene"
+    a = lib.ref_adapter_desc(h_).contents
+    assert (a.struct_size, a.n_objects, a.n_nodes, a.n_refs, a.n_out_of_tree, a.n_transforms) == \
+           (d.struct_size, d.n_objects, d.n_nodes, d.n_refs, d.n_out_of_tree, d.n_transforms)
+    n = d.n_objects
+
+    def same(pa, pb, shape, dtype):
+        x = np.ctypeslib.as_array(C.cast(pa, C.POINTER(dtype)), shape=shape)
+        y = np.ctypeslib.as_array(C.cast(pb, C.POINTER(dtype)), shape=shape)
+        return np.array_equal(x, y)
+
+    assert same(a.obj_kind, d.obj_kind, (n,), C.c_uint8)
+    assert same(a.obj_transform, d.obj_transform, (n,), C.c_uint32)
+    for field, width in (("tri_p", 9), ("tri_n", 9), ("tri_uv", 6), ("sphere", 4)):
+        assert same(getattr(a, field), getattr(d, field), (n * width,), C.c_uint32), field
+    assert same(a.transforms, d.transforms, (d.n_transforms * 21,), C.c_uint32)
+    assert same(a.nodes, d.nodes, (d.n_nodes * 2,), C.c_uint32)
+    assert same(a.refs, d.refs, (d.n_refs,), C.c_uint32)
+    if d.n_out_of_tree:
+        assert same(a.out_of_tree, d.out_of_tree, (d.n_out_of_tree,), C.c_uint32)
+    assert bits(np.array(a.root_min)).tolist() == bits(np.array(d.root_min)).tolist()
+    assert bits(np.array(a.root_max)).tolist() == bits(np.array(d.root_max)).tolist()
+    # RefScene gives every object its own material (index = object index) with the product's emission
+    om = np.ctypeslib.as_array(a.obj_material, shape=(n,))
+    assert np.array_equal(om, np.arange(n))
+    pm = np.ctypeslib.as_array(d.obj_material, shape=(n,))
+    for i in range(0, n, max(1, n // 50)):
+        assert tuple(a.materials[i].emission) == tuple(d.materials[int(pm[i])].emission)
+    if cam:
+        assert a.has_camera == 1
+        for f in ("pos", "near_top_left", "dx_pixel", "dy_pixel", "x_dir", "up"):
+            close(np.array(getattr(a.camera, f), np.float32), np.array(getattr(d.camera, f), np.float32), rel=2e-6, abs_=1e-7)
+    lib.ref_adapter_free(h_)
