@@ -86,6 +86,22 @@ def build_ref(force=False):
     return REF_SO
 
 
+SANITIZE_BIN = os.path.join(ROOT, "tests", "sanitize", "host_sanitize")
+
+
+def build_sanitize(force=False):
+    """The host library's sources and tests/sanitize/host_sanitize.cpp compiled together with
+    AddressSanitizer + UndefinedBehaviorSanitizer (host code only; GPU sanitizers are not available)."""
+    host_dir = os.path.join(CSRC, "host")
+    srcs = _files(host_dir, (".cpp",)) + [os.path.join(ROOT, "tests", "sanitize", "host_sanitize.cpp")]
+    deps = srcs + _files(host_dir, (".hpp",)) + _files(INC, (".h", ".hpp")) + [HIP_SO]
+    if force or _newer(SANITIZE_BIN, deps):
+        _run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+              "-fno-sanitize-recover=undefined", "-fopenmp", "-ffp-contract=off", "-I" + INC, "-I" + host_dir, "-o", SANITIZE_BIN] + srcs +
+             ["-L" + PKG, "-lmrt_hip", "-Wl,-rpath," + PKG])
+    return SANITIZE_BIN
+
+
 def build_all(force=False):
     build_hip(force)
     build_host(force)
