@@ -336,6 +336,17 @@ enum {
 };
 mrt_status mrt_debug_eval( mrt_scene* scene, uint32_t fn, uint32_t n, const float* in, uint32_t in_stride, float* out, uint32_t out_stride );
 
+/* What the library found out about the device of `scene` (diagnostics): xcd_mask = the value for
+ * which blockIdx.x & xcd_mask names the XCD a workgroup runs on (7 on an unpartitioned MI355X),
+ * probed from the XCC_ID hardware register at mrt_scene_create. */
+typedef struct mrt_device_info {
+    int32_t device;
+    int32_t compute_units;
+    uint32_t xcd_mask;
+    uint32_t kd_tree_depth;
+} mrt_device_info;
+mrt_status mrt_scene_device_info( const mrt_scene* scene, mrt_device_info* out );
+
 const char* mrt_last_error( void );
 int32_t mrt_version( void );
 

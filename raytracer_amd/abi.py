@@ -98,6 +98,10 @@ class RenderStats(C.Structure):
                 ("passes", C.c_uint64)]
 
 
+class DeviceInfo(C.Structure):
+    _fields_ = [("device", C.c_int32), ("compute_units", C.c_int32), ("xcd_mask", C.c_uint32), ("kd_tree_depth", C.c_uint32)]
+
+
 _hip = None
 _host = None
 
@@ -125,6 +129,8 @@ def hip():
         lib.mrt_render.restype = C.c_int32
         lib.mrt_resolve.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.mrt_resolve.restype = C.c_int32
+        lib.mrt_scene_device_info.argtypes = [C.c_void_p, C.POINTER(DeviceInfo)]
+        lib.mrt_scene_device_info.restype = C.c_int32
         lib.mrt_reduce.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.c_int32]
         lib.mrt_reduce.restype = C.c_int32
         lib.mrt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]

@@ -40,15 +40,16 @@ struct PathState {
     // path
     float *tpx, *tpy, *tpz; // throughput
     float *Lx, *Ly, *Lz;    // radiance so far
-    uint64_t *rng_state, *rng_inc;
+    uint64_t* rng_state; // PCG32 state of the sample's engine stream (its increment follows from the sample's key)
     // pending direct lighting of the last shaded bounce: L += (ptp * di) / pick_pdf
     float *ptx, *pty, *ptz, *dix, *diy, *diz, *pick_pdf;
     uint32_t* pending;
-    // factors of the MIS ray's contribution
+    // factors of the MIS ray's contribution; in a scene without emissive objects (mb) is the whole
+    // contribution the ray makes if it escapes, and mw, mpdf, mlight are unused
     float *mbx, *mby, *mbz, *mw, *mpdf;
     uint32_t* mlight;
 };
-#define MRT_PATH_WORDS 52
+#define MRT_PATH_WORDS 50
 
 MRT_DEV void put_ray( float4* r0, float4* r1, uint32_t id, V3 o, V3 d, float tmax ) {
     r0[id] = make_float4( o.x, o.y, o.z, d.x );
@@ -159,6 +160,9 @@ struct RenderCounters {
 #ifndef MRT_SHADE_WAVES
 #define MRT_SHADE_WAVES 4 // waves per SIMD the shade kernel is compiled for
 #endif
+#ifndef MRT_SHADE_RUN
+#define MRT_SHADE_RUN 2u // consecutive blocks of paths a block of a later bounce draws at a time
+#endif
 #endif
 MRT_DEV void queue_push3( uint32_t* const* queue, uint32_t* counters, const bool* take, uint32_t id ) {
     __shared__ uint32_t s_cnt[3][MRT_SHADE_BLOCK / 64];
@@ -196,19 +200,14 @@ __global__ void __launch_bounds__( 256 ) generate_kernel( PathState ps, PassInfo
     const uint32_t pixel  = y * pi.width + x;
     const uint32_t sample = pi.sample_begin + s_local;
     const uint64_t key    = pixel_key( pi.seed, pixel );
-    Pcg32 rng;
-    pcg_set_sequence( rng, sample_sequence( key, sample ) );
     // Sampler::GetCameraSample (sampler.cpp:43-49): 2D dim 0, 1D dim 0 (time, unused), 2D dim 1
     V2 jit  = strat2d( key, 0, sample, pi.spp_x, pi.spp_y );
     V2 lens = strat2d( key, 1, sample, pi.spp_x, pi.spp_y );
     V3 o, d;
     camera_ray( cam, (float)x + jit.x, (float)y + jit.y, lens.x, lens.y, o, d );
+    // throughput 1, radiance 0, no pending term and the start of the engine stream are what the
+    // first shade of a path assumes without reading them
     put_ray( ps.ray0, ps.ray1, id, o, d, 100000.f );
-    ps.tpx[id] = ps.tpy[id] = ps.tpz[id] = 1.f;
-    ps.Lx[id] = ps.Ly[id] = ps.Lz[id] = 0.f;
-    ps.rng_state[id] = rng.state;
-    ps.rng_inc[id]   = rng.inc;
-    ps.pending[id]   = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,24 +235,65 @@ __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_ker
 }
 
 // ------------------------------------------------------------------------------------------------
+// The pending word of a path: byte 0 = a direct-lighting term is pending, byte 2 = its MIS ray
+// escaped (written, as a single byte, by connect_mis_occlusion; the term shade stored in mb for that
+// case is then part of DI).  shade writes the whole word, which clears byte 2.
+#define MRT_PENDING 0x000000ffu
+#define MRT_PENDING_MIS_ESCAPED 0x00ff0000u
 MRT_DEV void fold_pending( PathState& ps, uint32_t id, V3& L ) {
-    if ( !ps.pending[id] ) return;
+    const uint32_t w = ps.pending[id];
+    if ( !( w & MRT_PENDING ) ) return;
     // ret += throughput * directIllumination(...) / lightPdf   (integrator.cpp:169-177)
     V3 tp = mk3( ps.ptx[id], ps.pty[id], ps.ptz[id] ), di = mk3( ps.dix[id], ps.diy[id], ps.diz[id] );
+    if ( w & MRT_PENDING_MIS_ESCAPED ) di = di + mk3( ps.mbx[id], ps.mby[id], ps.mbz[id] ); // integrator.cpp:114-117
     L     = L + ( tp * di ) / ps.pick_pdf[id];
     ps.pending[id] = 0;
 }
 
-__global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kernel( DTrace tr, DShade sh, PathState ps, PassInfo pi, Queues q, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t depth ) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = n_ptr ? *n_ptr : n_max;
+// One loop iteration of trace_ray for every live path of the bounce.
+// `chunks` == nullptr: one block per MRT_SHADE_BLOCK paths (the first bounce, whose path count the
+// host knows).  Otherwise the grid is sized for the chip and its blocks draw runs of
+// MRT_SHADE_RUN x MRT_SHADE_BLOCK paths from the counter `chunks` (zero at launch) until the live
+// paths, whose number is read from the device, are used up: a late bounce with few paths left costs
+// a short launch, and because the runs are handed out in order, the queues this kernel appends to
+// keep the order of the queue it reads (a fixed stride would let blocks with cheap paths run ahead,
+// and the next traversal kernels would find neighbouring rays far apart in their lists).
+// MIS_ESCAPE: the scene has no emissive object, so a MIS ray contributes only when it escapes, and
+// what it then contributes -- bsdf * Le(wi) * weight / pdf -- is known here: it is stored in mb and
+// connect_mis_occlusion adds it for the rays that escape (no mis_resolve pass; a MIS ray whose
+// contribution would be black is not traced at all).
+// FIRST: the first bounce (depth 0, identity queue, one block per MRT_SHADE_BLOCK paths).
+template <bool MIS_ESCAPE, bool FIRST>
+__global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kernel( DTrace tr, DShade sh, PathState ps, PassInfo pi, Queues q, const uint32_t* __restrict__ queue_, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t depth_, uint32_t* __restrict__ chunks_ ) {
+    const uint32_t depth           = FIRST ? 0u : depth_;
+    const uint32_t* const queue    = FIRST ? nullptr : queue_;
+    uint32_t* const chunks         = FIRST ? nullptr : chunks_;
+    const uint32_t n = ( !FIRST && n_ptr ) ? *n_ptr : n_max;
+    __shared__ uint32_t s_run;
+    for ( uint32_t step = 0;; step++ ) {
+    uint32_t base;
+    if ( chunks ) {
+        if ( step % MRT_SHADE_RUN == 0u ) {
+            if ( threadIdx.x == 0 ) s_run = atomicAdd( chunks, 1u );
+            __syncthreads(); // the next write of s_run comes after the barriers of queue_push3
+        }
+        base = ( s_run * MRT_SHADE_RUN + step % MRT_SHADE_RUN ) * MRT_SHADE_BLOCK;
+    }
+    else base = blockIdx.x * MRT_SHADE_BLOCK;
+    if ( base >= n || ( !chunks && step != 0u ) ) break;
+    const uint32_t i = base + threadIdx.x;
     bool alive = false, has_shadow = false, has_mis = false;
     uint32_t id = 0;
     if ( i < n ) {
         id = queue ? queue[i] : i;
-        V3 L = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
-        fold_pending( ps, id, L );
-        V3 tp = mk3( ps.tpx[id], ps.tpy[id], ps.tpz[id] );
+        // a path's first shade starts from radiance 0, throughput 1 and nothing pending
+        V3 L = mk3( 0.f ), tp = mk3( 1.f );
+        if ( depth != 0 ) {
+            L = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
+            fold_pending( ps, id, L );
+            tp = mk3( ps.tpx[id], ps.tpy[id], ps.tpz[id] );
+        }
+        bool pending = false;
         V3 ro, rd;
         float ray_far;
         get_ray( ps.ray0, ps.ray1, id, ro, rd, ray_far );
@@ -266,9 +306,6 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
         else {
             Surf sf = surface_from_hit( tr, sh, ro, rd, h );
             const DMaterial mat = sh.materials[sf.material];
-            Pcg32 rng;
-            rng.state = ps.rng_state[id];
-            rng.inc   = ps.rng_inc[id];
             uint32_t s_local, p_local;
             pass_split( pi, id, s_local, p_local );
             uint32_t px, py;
@@ -276,6 +313,11 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
             const uint32_t pixel = py * pi.width + px;
             const uint32_t sample = pi.sample_begin + s_local;
             const uint64_t key    = pixel_key( pi.seed, pixel );
+            // the engine stream of the sample: its increment is a function of the sequence index,
+            // only the state travels with the path
+            Pcg32 rng;
+            pcg_set_sequence( rng, sample_sequence( key, sample ) );
+            if ( depth != 0 ) rng.state = ps.rng_state[id];
 
             // integrator.cpp:147-150
             if ( !is_black( ld3( mat.emission ) ) && depth == 0 ) {
@@ -344,18 +386,31 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
                             float weight = power_heuristic( scatteringPdf, lp );
                             V3 m_o       = sf.position + ( wi * MRT_ACNE_EPS );
                             V3 m_d       = normalize3( wi );
-                            has_mis      = true;
-                            put_ray( ps.mray0, ps.mray1, id, m_o, m_d, 10000.f );
-                            ps.mbx[id] = bsdf.x, ps.mby[id] = bsdf.y, ps.mbz[id] = bsdf.z;
-                            ps.mw[id]     = weight;
-                            ps.mpdf[id]   = scatteringPdf;
-                            ps.mlight[id] = (uint32_t)li;
+                            if ( MIS_ESCAPE ) {
+                                // integrator.cpp:108-117 for a ray that hits nothing: Li = light->Le(ray),
+                                // black for a shape light
+                                V3 Le = light.kind == 1 ? ibl_Le( sh, m_d ) : mk3( 0.f );
+                                if ( !is_black( Le ) ) {
+                                    V3 c    = bsdf * Le * weight / scatteringPdf;
+                                    has_mis = true;
+                                    put_ray( ps.mray0, ps.mray1, id, m_o, m_d, 10000.f );
+                                    ps.mbx[id] = c.x, ps.mby[id] = c.y, ps.mbz[id] = c.z;
+                                }
+                            }
+                            else {
+                                has_mis = true;
+                                put_ray( ps.mray0, ps.mray1, id, m_o, m_d, 10000.f );
+                                ps.mbx[id] = bsdf.x, ps.mby[id] = bsdf.y, ps.mbz[id] = bsdf.z;
+                                ps.mw[id]     = weight;
+                                ps.mpdf[id]   = scatteringPdf;
+                                ps.mlight[id] = (uint32_t)li;
+                            }
                         }
                     }
                     ps.ptx[id] = tp.x, ps.pty[id] = tp.y, ps.ptz[id] = tp.z;
                     ps.dix[id] = di.x, ps.diy[id] = di.y, ps.diz[id] = di.z;
                     ps.pick_pdf[id] = lightPickPdf;
-                    ps.pending[id]  = 1;
+                    pending         = true;
                 }
             }
             // integrator.cpp:180-193
@@ -365,18 +420,23 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
             wi        = normalize3( wi );
             if ( !( is_black( bsdf ) || pdf == 0.f ) ) {
                 if ( mat.type != 2 ) tp = tp * ( bsdf * fabsf( dot3( wi, sf.normal ) ) / pdf );
-                V3 no = sf.position + MRT_ACNE_EPS * wi;
-                put_ray( ps.ray0, ps.ray1, id, no, wi, 10000.f );
-                ps.tpx[id] = tp.x, ps.tpy[id] = tp.y, ps.tpz[id] = tp.z;
                 alive = depth < pi.max_depth; // integrator.cpp:201
+                if ( alive ) {
+                    V3 no = sf.position + MRT_ACNE_EPS * wi;
+                    put_ray( ps.ray0, ps.ray1, id, no, wi, 10000.f );
+                    ps.tpx[id] = tp.x, ps.tpy[id] = tp.y, ps.tpz[id] = tp.z;
+                    ps.rng_state[id] = rng.state;
+                }
             }
-            ps.rng_state[id] = rng.state;
         }
+        // fold_pending cleared the flag of a later bounce; the first one finds it unwritten
+        if ( pending || depth == 0 ) ps.pending[id] = pending ? 1u : 0u; // the whole word: no MIS ray has escaped yet
         ps.Lx[id] = L.x, ps.Ly[id] = L.y, ps.Lz[id] = L.z;
     }
     uint32_t* const queues[3] = { q.next, q.shadow, q.mis };
     const bool take[3]        = { alive, has_shadow, has_mis };
     queue_push3( queues, q.counts, take, id );
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,9 +501,9 @@ struct MisOcclusionIO {
         get_ray( ps.mray0, ps.mray1, id, o, d, t1 );
         t0 = 0.f;
     }
+    // an escaped ray makes the contribution shade computed for that case: one byte tells the fold
     MRT_DEV void store( uint32_t id, bool found, const DHit& ) const {
-        // object 0 stands for "some non-emissive object"
-        ps.hit[id] = make_float4( __uint_as_float( found ? 0u : 0xffffffffu ), 0.f, 0.f, 0.f );
+        if ( !found ) ( (uint8_t*)ps.pending )[4u * id + 2u] = 1;
     }
 };
 

@@ -82,6 +82,10 @@ struct DTrace {
     float root_min[3];
     float root_max[3];
     uint32_t root[8]; // record 0: every ray starts from it without a load
+    // workgroups go to the device's XCDs round-robin: blockIdx.x & xcd_mask names the XCD a block
+    // runs on (7 on an unpartitioned MI355X; probed per device at scene creation, 0 = unknown
+    // mapping or a single XCD)
+    uint32_t xcd_mask;
 };
 
 struct DHit {
@@ -282,7 +286,7 @@ MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
 // MRT_TRACE_LDS_WORDS( BOOL_ONLY ) 32-bit words.
 //
 // Dealing: the list is cut into runs of MRT_DEAL_RUN chunks of MRT_CHUNK rays, dealt round-robin to eight
-// parts, one per XCD (workgroups go to the XCDs round-robin, so blockIdx.x & 7 names the XCD), each
+// parts, one per XCD (workgroups go to the XCDs round-robin, so blockIdx.x & DTrace::xcd_mask names the XCD), each
 // with a counter in `deal` (eight counters MRT_DEAL_STRIDE words apart, zero at launch).  A wave
 // draws the next chunk of its XCD's part, and of the following parts once that one is exhausted.
 // The rays in flight on one XCD are therefore consecutive in the list - for path tracing:
@@ -348,7 +352,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         if ( !more && n_idle == 64u ) break;
         if ( more && n_idle >= MRT_REFILL_MIN ) {
             while ( left == 0 && part_try < 8u ) {
-                const uint32_t part = ( ( blockIdx.x & 7u ) + part_try ) & 7u;
+                const uint32_t part = ( ( blockIdx.x & s.xcd_mask ) + part_try ) & 7u;
                 uint32_t got        = 0;
                 if ( __lane_id() == 0 ) got = atomicAdd( deal + part * MRT_DEAL_STRIDE, 1u );
                 got                 = (uint32_t)__builtin_amdgcn_readfirstlane( (int)got );

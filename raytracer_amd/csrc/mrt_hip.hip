@@ -195,6 +195,54 @@ mrt_status build_tree_records( const mrt_scene_desc* d, std::vector<uint4>& node
 
 } // namespace
 
+// One lane per block reports the XCC_ID hardware register (bits 3:0 of hardware register 20 on
+// gfx942 / gfx950): which XCD the block was placed on.
+__global__ void xcd_probe_kernel( uint32_t* __restrict__ out ) {
+    if ( threadIdx.x == 0 ) out[blockIdx.x] = (uint32_t)__builtin_amdgcn_s_getreg( 20 | ( 0 << 6 ) | ( 3 << 11 ) );
+}
+
+namespace {
+// blockIdx.x & mask = the XCD of a block, for the current device: 2^k - 1 when the first 64 blocks
+// of a grid land on 2^k XCDs round-robin (7 on an unpartitioned MI355X, 3 or 1 or 0 in the
+// partitioned modes), 0 when the placement follows no such rule.  The traversal kernels use it only
+// to choose which part of a ray list a wave draws from first, so a wrong mask costs locality, never
+// correctness.  Probed once per device.
+mrt_status xcd_mask_for_device( int device, uint32_t* mask_out ) {
+    static int cached[64];
+    static bool have[64] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock( mu );
+    if ( device >= 0 && device < 64 && have[device] ) {
+        *mask_out = (uint32_t)cached[device];
+        return MRT_OK;
+    }
+    constexpr int N = 64;
+    DevBuf<uint32_t> buf;
+    HIP_TRY( buf.alloc( N ) );
+    HIP_TRY( hipMemset( buf.p, 0xff, N * sizeof( uint32_t ) ) );
+    hipLaunchKernelGGL( xcd_probe_kernel, dim3( N ), dim3( 64 ), 0, 0, buf.p );
+    HIP_TRY( hipGetLastError() );
+    uint32_t id[N];
+    HIP_TRY( hipMemcpy( id, buf.p, sizeof( id ), hipMemcpyDeviceToHost ) );
+    uint32_t mask = 0;
+    for ( int n = 8; n >= 2; n /= 2 ) {
+        bool ok = true;
+        for ( int a = 0; a < n && ok; a++ )
+            for ( int b = 0; b < a && ok; b++ )
+                ok = id[a] != id[b]; // n distinct XCDs ...
+        for ( int b = n; b < N && ok; b++ )
+            ok = id[b] == id[b % n]; // ... visited round-robin
+        if ( ok ) {
+            mask = (uint32_t)n - 1u;
+            break;
+        }
+    }
+    if ( device >= 0 && device < 64 ) cached[device] = (int)mask, have[device] = true;
+    *mask_out = mask;
+    return MRT_OK;
+}
+} // namespace
+
 static mrt_status upload_shading( const mrt_scene_desc* d, mrt_scene* s ); // render_host.inc
 namespace {
 void free_workspace( RenderWorkspace& w );
@@ -321,6 +369,10 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     t.n_nodes     = d->n_nodes;
     t.n_out       = d->n_out_of_tree;
     t.n_xforms    = d->n_transforms;
+    {
+        mrt_status xs = xcd_mask_for_device( device, &t.xcd_mask );
+        if ( xs != MRT_OK ) return xs;
+    }
     for ( int k = 0; k < 8; k++ )
         t.root[k] = 0;
     if ( !nodes.empty() ) {
@@ -335,6 +387,15 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     mrt_status ss = upload_shading( d, s.get() );
     if ( ss != MRT_OK ) return ss;
     *out = s.release();
+    return MRT_OK;
+}
+
+mrt_status mrt_scene_device_info( const mrt_scene* scene, mrt_device_info* out ) {
+    if ( !scene || !out ) return fail( MRT_ERR_INVALID, "NULL argument" );
+    out->device        = scene->device;
+    out->compute_units = scene->n_cus;
+    out->xcd_mask      = scene->trace.xcd_mask;
+    out->kd_tree_depth = scene->tree_depth;
     return MRT_OK;
 }
 

@@ -299,3 +299,19 @@ def test_successive_calls_on_different_streams_are_ordered(small_bunny):
         for g, w in zip(b, want_any):
             assert torch.equal(g, w)
     dev.close()
+
+
+def test_device_probe_reports_the_xcd_mapping(cornell):
+    """An unpartitioned MI355X places the workgroups of a grid on its 8 XCDs round-robin; the probe
+    made at scene creation must find that (mask 7) or another power-of-two rule -- the traversal
+    kernels start each wave on its own XCD's part of the ray list."""
+    import ctypes as C
+    from raytracer_amd import abi
+    sc, tree = cornell
+    dev = DeviceScene(tree.flatten(1))
+    info = abi.DeviceInfo()
+    assert abi.hip().mrt_scene_device_info(dev._h, C.byref(info)) == abi.MRT_OK
+    assert info.compute_units > 0 and info.xcd_mask in (0, 1, 3, 7)
+    if info.compute_units == 256:
+        assert info.xcd_mask == 7
+    dev.close()
