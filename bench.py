@@ -97,10 +97,12 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
     img = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def timed(params, steps):
+    def timed(params, steps, serial=False):
         """`steps` frames bracketed by barrier + synchronize; returns (seconds max over ranks, rays and
-        paths summed over ranks, this rank's per-class kernel ms)."""
+        paths summed over ranks, this rank's per-class kernel ms, passes).  serial: one kernel at a
+        time (MRT_RENDER_SERIAL), which is when the per-class kernel times are each kernel's own."""
         params.paths_per_pass = args.paths_per_pass
+        params.flags = abi.MRT_RENDER_SERIAL if (serial or args.serial) else 0
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -137,12 +139,26 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
     own = None
     if rank == 0 and with_cpu:
         sp = render_params(WIDTH, HEIGHT, spp_x, spp_y * world, max_depth=MAX_DEPTH, seed=SEED, sample_begin=0,
-                           sample_end=min(spp, 256), flags=abi.MRT_RENDER_TRACE_STATS)
+                           sample_end=min(spp, 256), flags=abi.MRT_RENDER_TRACE_STATS | abi.MRT_RENDER_SERIAL)
         sp.paths_per_pass = args.paths_per_pass
         scratch = torch.zeros_like(img)
         own = dev.render(sp, scratch, stream=stream)
         del scratch
     elapsed, total_rays, total_paths, kms, n_passes = timed(weak, args.steps)
+    # The timed frames trace the three ray lists of a bounce side by side, so their per-class times
+    # overlap.  One more, untimed, frame with one kernel at a time gives every kernel's own duration
+    # (kernel_ms_per_step and the roofline come from it; rank-local, no collective).
+    if not args.serial and rank == 0:
+        import copy
+        solo = copy.copy(weak)
+        solo.paths_per_pass = args.paths_per_pass
+        solo.flags = abi.MRT_RENDER_SERIAL
+        tmp = torch.zeros_like(img)
+        rs = dev.render(solo, tmp, stream=stream)
+        torch.cuda.synchronize()
+        del tmp
+        kms = {"generate": rs.generate_ms * args.steps, "extend": rs.extend_ms * args.steps, "shade": rs.shade_ms * args.steps,
+               "connect": rs.connect_ms * args.steps, "connect_mis": rs.connect_mis_ms * args.steps}
     mean_radiance = float(img.mean().item()) / (spp * world) if rank == 0 else 0.0
 
     strong = None
@@ -175,6 +191,9 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
         "rays_per_path": total_rays / max(total_paths, 1.0),
         "mean_radiance": mean_radiance,
         "kernel_ms_per_step": {k: per_step[k] for k in ("generate", "extend", "shade", "connect")},
+        "kernel_ms_note": "device time of each kernel class running alone (one untimed frame with MRT_RENDER_SERIAL); the timed frames "
+                          "overlap the shadow, MIS and next-bounce traversal launches, so their sum exceeds ms_per_step" if not args.serial
+                          else "all frames rendered with MRT_RENDER_SERIAL (one kernel at a time)",
     }
     if name == "million_bunny":
         # measured, not extrapolated: one step of the N = 1 run IS 1024 spp at 1080p
@@ -231,6 +250,7 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
                 "avg_launch_ms": ms / launches if launches else None,
                 "algorithmic_bytes_per_launch": byts / launches if launches else None,
                 "bytes_per_ray": bpr, "reference_bytes_per_ray": ref_bytes_per_ray,
+                "timing": "kernel alone on the device (MRT_RENDER_SERIAL frame)",
                 "note": "achieved = ALGORITHMIC bytes (52 + 8*inner + 8*leaves + 4*refs + 36*prim_tests per ray, visits counted by the "
                         "kernels themselves on an untimed pass) of the kernel's launches of one step / their summed HIP-event time: a "
                         "gather rate, most of it served by L2 and the memory-side cache.  traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per "
@@ -254,6 +274,8 @@ def main():
     ap.add_argument("--workload", default="million_bunny", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and roofline legs")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] measurement")
+    ap.add_argument("--serial", action="store_true", help="render every frame with one kernel at a time (profiling runs: per-kernel "
+                                                          "durations of a kernel trace are then each kernel's own)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU sample (0 = the workload's default)")
     ap.add_argument("--spp-y", type=int, default=0, help="rows of the sample grid (profiling runs use fewer)")
     ap.add_argument("--paths-per-pass", type=int, default=0, help="paths in flight per pass (0 = library default)")

@@ -18,6 +18,7 @@ MRT_LIGHT_SHAPE, MRT_LIGHT_IBL = 0, 1
 MRT_BUF_HOST, MRT_BUF_DEVICE = 0, 1
 MRT_CLOSEST_HIT, MRT_ANY_HIT = 0, 1
 MRT_RENDER_TRACE_STATS = 1
+MRT_RENDER_SERIAL = 2
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)

@@ -92,6 +92,10 @@ struct mrt_scene {
     // it waits on `order` when it starts and records it when it has queued its work, so calls made
     // one after another on DIFFERENT streams are still executed in call order.
     hipEvent_t order = nullptr;
+    // mrt_render: side streams for the connection kernels, with the events that fork them from and
+    // join them to the caller's stream
+    hipStream_t side[2] = { nullptr, nullptr };
+    hipEvent_t fork = nullptr, join[2] = { nullptr, nullptr };
     uint64_t* d_stats = nullptr; // mrt_intersect: 8 x u64 traversal counters, then the MRT_DEAL_WORDS chunk counters
     uint32_t tree_depth = 0;
     int n_cus           = 256;
@@ -251,6 +255,11 @@ mrt_status scratch_for_device( int device, uint32_t** out ); // with mrt_interse
 mrt_scene::~mrt_scene() {
     if ( d_stats ) (void)hipFree( d_stats );
     if ( order ) (void)hipEventDestroy( order );
+    if ( fork ) (void)hipEventDestroy( fork );
+    for ( int k = 0; k < 2; k++ ) {
+        if ( join[k] ) (void)hipEventDestroy( join[k] );
+        if ( side[k] ) (void)hipStreamDestroy( side[k] );
+    }
     free_workspace( ws );
 }
 
@@ -359,6 +368,11 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     HIP_TRY( hipMalloc( (void**)&s->d_stats, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ) ) );
     HIP_TRY( hipEventCreateWithFlags( &s->order, hipEventDisableTiming ) );
     HIP_TRY( hipEventRecord( s->order, 0 ) );
+    HIP_TRY( hipEventCreateWithFlags( &s->fork, hipEventDisableTiming ) );
+    for ( int k = 0; k < 2; k++ ) {
+        HIP_TRY( hipStreamCreateWithFlags( &s->side[k], hipStreamNonBlocking ) );
+        HIP_TRY( hipEventCreateWithFlags( &s->join[k], hipEventDisableTiming ) );
+    }
 
     DTrace& t     = s->trace;
     t.nodes       = s->nodes.p;

@@ -482,3 +482,28 @@ def test_multi_device_reduce_and_split_render():
     assert np.array_equal(imgs[0].cpu().numpy(), host[0]) and np.array_equal(imgs[2].cpu().numpy(), host[2])
     assert abi.hip().mrt_reduce(handles, ptrs, 3, 1000, 3) != abi.MRT_OK  # root out of range
     dev.close()
+
+
+@pytest.mark.parametrize("scene", ["cornell", "bunny_env"])
+def test_overlapped_and_serial_execution_give_the_same_frame(scene):
+    """By default the shadow, MIS and next-bounce ray lists of a bounce are traced side by side on the
+    handle's internal streams; MRT_RENDER_SERIAL runs one kernel at a time.  Same bits either way,
+    with emitters (MIS hits share the hit record with the next extend: only the two connection
+    kernels overlap) and without (all three overlap), over several passes."""
+    import torch
+    sc = scenes.cornell(96, 96) if scene == "cornell" else scenes.small_bunny(96, 96, env_pixels=scenes.synthetic_env())
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    frames = []
+    for flags in (0, abi.MRT_RENDER_SERIAL, 0):
+        img = torch.zeros((96, 96, 3), dtype=torch.float32, device="cuda")
+        p = render_params(96, 96, 4, 4, max_depth=5, seed=13, paths_per_pass=96 * 96 * 5, flags=flags)
+        rs = dev.render(p, img)
+        torch.cuda.synchronize()
+        frames.append((img.cpu().numpy(), rs.rays_closest, rs.rays_any, rs.passes))
+    assert frames[0][3] == 4
+    for f in frames[1:]:
+        assert np.array_equal(f[0], frames[0][0]) and f[1:] == frames[0][1:]
+    cpu, crs, _, _ = orc.oracle_render(flat.desc, render_params(96, 96, 4, 4, max_depth=5, seed=13), 0, threads=16)
+    check_images(frames[0][0], cpu, 16)
+    dev.close()

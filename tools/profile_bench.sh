@@ -7,9 +7,9 @@ out=${1:-gpurun_out/prof_bench}
 wl=${2:-million_bunny}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --workload $wl --no-secondary > $out/bench.log 2>&1 || { echo "trace run failed"; tail -5 $out/bench.log; exit 1; }
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --workload $wl --no-secondary --serial > $out/bench.log 2>&1 || { echo "trace run failed"; tail -5 $out/bench.log; exit 1; }
 echo "trace done"
-short="--workload $wl --no-secondary --steps 1 --warmup 0 --no-cpu"
+short="--workload $wl --no-secondary --serial --steps 1 --warmup 0 --no-cpu"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 400 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python3 bench.py $short > $out/$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out/$c.log; exit 1; }
   echo "pass $c done"
