@@ -379,5 +379,8 @@ class HIPRenderer : public ImageRenderer
 };
 
 bool savePPM( const char* filename, const float* rgb, uint32_t w, uint32_t h ); // 8-bit, clamp like image.cpp:137
+// saveImage (image.cpp:60-146): the same 8-bit conversion, written as a PNG (8-bit RGB, stored
+// deflate blocks; any PNG reader, lodepng included, decodes it to the same bytes)
+bool savePNG( const char* filename, const float* rgb, uint32_t w, uint32_t h );
 
 } // namespace mrt

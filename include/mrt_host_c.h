@@ -85,6 +85,8 @@ int mrth_intersect_kdtree( void* scene, void* tree, const float* o3, const float
  * Returns the number of steps, -1 on failure. */
 int mrth_hip_render_progressive( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, uint32_t samples_per_step,
                                  int checkpoint_after, const char* checkpoint_path, float* rgb_sum, mrt_render_stats* stats );
+/* savePNG: linear or gamma-encoded floats [h][w][3] -> 8-bit RGB PNG as saveImage writes it (image.cpp:127-146). */
+int mrth_save_png( const char* filename, const float* rgb, uint32_t w, uint32_t h );
 int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, float* rgb_sum, mrt_render_stats* stats, double* seconds );
 /* The same with HIPRenderer::devices: the samples are divided among the listed devices (a device
  * may be listed more than once: one handle, with its own workspace, per entry). */

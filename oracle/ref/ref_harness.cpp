@@ -723,4 +723,27 @@ void ref_material_set_checker( void* scene_, int mat, const float* even3, const 
     scene->m_Materials[mat].m_MatModel = MaterialModel::COOK_TORRANCE;
 }
 
+// ---------------------------------------------------------------- image.cpp
+// loadPng (image.cpp:14-41) of a file: width, height and the float pixels (byte / 255).
+int ref_load_png( const char* path, int* w, int* h, float* rgb, int64_t capacity_floats ) {
+    RenderImage* img = loadPng( path );
+    if ( !img ) return -1;
+    *w = (int)img->width, *h = (int)img->height;
+    const int64_t n = 3 * (int64_t)img->width * img->height;
+    if ( rgb && n <= capacity_floats )
+        for ( size_t i = 0; i < img->width * img->height; i++ )
+            put3( rgb + 3 * i, img->data[i] );
+    freeImage( img );
+    return 0;
+}
+// saveImage (image.cpp:60-146) of float pixels: writes <basename>.png
+void ref_save_image( const char* basename, int w, int h, const float* rgb ) {
+    RenderImage* img = initImage( w, h );
+    for ( size_t i = 0; i < (size_t)w * h; i++ )
+        img->data[i] = color3( rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] );
+    std::string name( basename );
+    saveImage( img, name.data() );
+    freeImage( img );
+}
+
 } // extern "C"

@@ -190,6 +190,7 @@ def host():
             "mrth_intersect_kdtree": (ci, [vp, vp, f32p, f32p, C.c_float, C.c_float, ci, f32p]),
             "mrth_hip_render": (ci, [vp, C.c_uint32, C.c_uint32, ci, ci, ci, C.c_uint32, ci, f32p,
                                      C.POINTER(RenderStats), C.POINTER(C.c_double)]),
+            "mrth_save_png": (ci, [C.c_char_p, f32p, C.c_uint32, C.c_uint32]),
             "mrth_hip_render_devices": (ci, [vp, C.c_uint32, C.c_uint32, ci, ci, ci, C.c_uint32, C.POINTER(C.c_int), ci, f32p,
                                              C.POINTER(RenderStats), C.POINTER(C.c_double)]),
             "mrth_hip_render_progressive": (ci, [vp, C.c_uint32, C.c_uint32, ci, ci, ci, C.c_uint32, ci, C.c_uint32, ci,

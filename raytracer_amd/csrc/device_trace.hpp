@@ -37,7 +37,9 @@
 #pragma once
 #include "device_math.hpp"
 
-#define MRT_STACK_MAX 64
+#ifndef MRT_STACK_MAX
+#define MRT_STACK_MAX 128 // deferred nodes per ray: trees up to depth 126 (the entries beyond the LDS part live in scratch)
+#endif
 #define MRT_ACNE_EPS 1e-4f
 #ifndef MRT_XF_LDS
 #define MRT_XF_LDS 16 // transforms kept in LDS (12 floats each); the rest are read from HBM
@@ -77,6 +79,7 @@ struct DTrace {
     const DXf* xforms;
     const uint32_t* out_of_tree;
     uint32_t n_nodes;
+    uint32_t n_records; // 32-byte records in `nodes` (at least 1 when n_nodes != 0)
     uint32_t n_out;
     uint32_t n_xforms;
     float root_min[3];
@@ -120,8 +123,14 @@ struct DStats {
 #ifndef MRT_TRACE_WAVES
 #define MRT_TRACE_WAVES 6 // waves per SIMD the traversal kernels are compiled for (register budget)
 #endif
+// MRT_TOP_LDS: tree records 1 .. MRT_TOP_LDS (the levels right below the root record, which every
+// ray steps through; the caller's breadth-first top layout numbers them first) staged in LDS, 8 words
+// each, and read from there instead of through the vector memory path.  0 = none.
+#ifndef MRT_TOP_LDS
+#define MRT_TOP_LDS 0
+#endif
 #define MRT_TRACE_LDS_WORDS( BOOL_ONLY ) \
-    ( MRT_XF_LDS * 12 + ( ( BOOL_ONLY ) ? MRT_STACK_LDS_BOOL * MRT_TRACE_BLOCK * 2 : MRT_STACK_LDS * MRT_TRACE_BLOCK * 2 + MRT_TRACE_BLOCK * 7 ) )
+    ( MRT_XF_LDS * 12 + MRT_TOP_LDS * 8 + ( ( BOOL_ONLY ) ? MRT_STACK_LDS_BOOL * MRT_TRACE_BLOCK * 2 : MRT_STACK_LDS * MRT_TRACE_BLOCK * 2 + MRT_TRACE_BLOCK * 7 ) )
 
 typedef __attribute__( ( address_space( 3 ) ) ) uint32_t lds_u32;
 typedef __attribute__( ( address_space( 3 ) ) ) float lds_f32;
@@ -304,8 +313,17 @@ MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
 template <bool ANY, bool BOOL_ONLY, bool STATS, class IO>
 MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t n, uint32_t* deal, DStats& st ) {
     constexpr int NST          = BOOL_ONLY ? MRT_STACK_LDS_BOOL : MRT_STACK_LDS;
-    constexpr uint32_t LDS_STACK = MRT_XF_LDS * 12, LDS_OUT = LDS_STACK + NST * MRT_TRACE_BLOCK * 2, LDS_PL = LDS_OUT + MRT_TRACE_BLOCK * 3;
+    constexpr uint32_t LDS_TOP = MRT_XF_LDS * 12, LDS_STACK = LDS_TOP + MRT_TOP_LDS * 8, LDS_OUT = LDS_STACK + NST * MRT_TRACE_BLOCK * 2, LDS_PL = LDS_OUT + MRT_TRACE_BLOCK * 3;
     const lds_f32* xf_lds = (const lds_f32*)lds;
+#if MRT_TOP_LDS
+    {
+        // records 1 .. MRT_TOP_LDS as 8 words each (a tree with fewer records stages what it has)
+        const uint32_t n_rec = ( s.n_records - 1u < (uint32_t)MRT_TOP_LDS ) ? s.n_records - 1u : (uint32_t)MRT_TOP_LDS;
+        for ( uint32_t i = threadIdx.x; i < n_rec * 8u; i += blockDim.x )
+            lds[LDS_TOP + i] = ( (const uint32_t*)s.nodes )[8u + i];
+    }
+    const lds_f4* top_lds = (const lds_f4*)( lds + LDS_TOP );
+#endif
     stage_transforms( s, (lds_f32*)lds );
     lds_u2* stack_lds = (lds_u2*)( lds + LDS_STACK ) + threadIdx.x;
     // the records below exist only when !BOOL_ONLY
@@ -586,8 +604,18 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         }
         if ( want_node ) {
             cur = node;
-            L0  = ld_node( s, node, 0 );
-            L1  = ld_node( s, node, 1 );
+#if MRT_TOP_LDS
+            if ( node - 1u < (uint32_t)MRT_TOP_LDS ) { // node 0 is never asked for: every ray starts in it
+                const v4f a0 = top_lds[( node - 1u ) * 2u], a1 = top_lds[( node - 1u ) * 2u + 1u];
+                L0 = make_float4( a0.x, a0.y, a0.z, a0.w );
+                L1 = make_float4( a1.x, a1.y, a1.z, a1.w );
+            }
+            else
+#endif
+            {
+                L0 = ld_node( s, node, 0 );
+                L1 = ld_node( s, node, 1 );
+            }
         }
     }
 }

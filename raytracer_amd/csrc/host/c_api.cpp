@@ -319,6 +319,10 @@ int mrth_intersect_kdtree( void* scene, void* tree, const float* o3, const float
 }
 
 // HIPRenderer::init + run + destroy; rgb_sum receives the linear radiance sums.
+int mrth_save_png( const char* filename, const float* rgb, uint32_t w, uint32_t h ) {
+    return savePNG( filename, rgb, w, h ) ? 0 : -1;
+}
+
 int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, float* rgb_sum, mrt_render_stats* stats, double* seconds ) {
     return mrth_hip_render_devices( scene, w, h, spp_x, spp_y, max_depth, seed, &device, 1, rgb_sum, stats, seconds );
 }

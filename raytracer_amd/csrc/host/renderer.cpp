@@ -156,7 +156,7 @@ void HIPRenderer::run() {
     Render( (uint32_t)( spp_x * spp_y ) );
     seconds = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
     std::printf( "Rendering took %gs\n", seconds );
-    if ( !m_imageName.empty() ) savePPM( ( m_imageName + ".ppm" ).c_str(), m_image.data(), m_w, m_h );
+    if ( !m_imageName.empty() ) savePNG( ( m_imageName + ".png" ).c_str(), m_image.data(), m_w, m_h ); // saveImage( m_renderImage, m_imageName ), CPURenderer.cpp:83
 }
 
 namespace {

@@ -554,4 +554,79 @@ bool savePPM( const char* filename, const float* rgb, uint32_t w, uint32_t h ) {
     return true;
 }
 
+// ------------------------------------------------------------------ PNG (image.cpp:127-146)
+// saveImage converts every channel with ivec3(255.f * c) clamped to 0..255 and hands the bytes to
+// lodepng_encode24_file.  Same bytes here; the container is a minimal PNG: 8-bit RGB, no filtering,
+// the zlib stream made of stored (uncompressed) deflate blocks.
+namespace {
+uint32_t crc32_update( uint32_t crc, const unsigned char* p, size_t n ) {
+    static uint32_t table[256];
+    static bool init = false;
+    if ( !init ) {
+        for ( uint32_t i = 0; i < 256; i++ ) {
+            uint32_t c = i;
+            for ( int k = 0; k < 8; k++ )
+                c = ( c & 1u ) ? 0xedb88320u ^ ( c >> 1 ) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    for ( size_t i = 0; i < n; i++ )
+        crc = table[( crc ^ p[i] ) & 0xffu] ^ ( crc >> 8 );
+    return crc;
+}
+void put_be32( std::vector<unsigned char>& v, uint32_t x ) {
+    v.push_back( (unsigned char)( x >> 24 ) ), v.push_back( (unsigned char)( x >> 16 ) ), v.push_back( (unsigned char)( x >> 8 ) ), v.push_back( (unsigned char)x );
+}
+bool write_chunk( FILE* f, const char* type, const std::vector<unsigned char>& data ) {
+    std::vector<unsigned char> head;
+    put_be32( head, (uint32_t)data.size() );
+    uint32_t crc = crc32_update( 0xffffffffu, (const unsigned char*)type, 4 );
+    if ( !data.empty() ) crc = crc32_update( crc, data.data(), data.size() );
+    std::vector<unsigned char> tail;
+    put_be32( tail, crc ^ 0xffffffffu );
+    return std::fwrite( head.data(), 1, 4, f ) == 4 && std::fwrite( type, 1, 4, f ) == 4 &&
+           ( data.empty() || std::fwrite( data.data(), 1, data.size(), f ) == data.size() ) && std::fwrite( tail.data(), 1, 4, f ) == 4;
+}
+} // namespace
+
+bool savePNG( const char* filename, const float* rgb, uint32_t w, uint32_t h ) {
+    if ( w == 0 || h == 0 ) return false;
+    // scanlines: filter byte 0 + w * 3 bytes
+    const size_t row = (size_t)w * 3 + 1;
+    std::vector<unsigned char> raw( row * h );
+    for ( uint32_t y = 0; y < h; y++ ) {
+        raw[row * y] = 0;
+        for ( uint32_t i = 0; i < w * 3; i++ ) {
+            int c                  = (int)( 255.f * rgb[(size_t)y * w * 3 + i] );
+            raw[row * y + 1 + i] = (unsigned char)( c < 0 ? 0 : ( c > 255 ? 255 : c ) );
+        }
+    }
+    std::vector<unsigned char> z;
+    z.reserve( raw.size() + raw.size() / 65535 * 5 + 16 );
+    z.push_back( 0x78 ), z.push_back( 0x01 ); // zlib header: deflate, 32 KiB window, no preset dictionary
+    uint32_t a = 1, b = 0;                   // Adler-32 of the raw bytes
+    for ( size_t off = 0; off < raw.size(); ) {
+        const size_t len = std::min<size_t>( 65535, raw.size() - off );
+        z.push_back( off + len == raw.size() ? 1 : 0 ); // BFINAL, BTYPE = 00 (stored)
+        z.push_back( (unsigned char)( len & 0xff ) ), z.push_back( (unsigned char)( len >> 8 ) );
+        z.push_back( (unsigned char)( ~len & 0xff ) ), z.push_back( (unsigned char)( ( ~len >> 8 ) & 0xff ) );
+        z.insert( z.end(), raw.begin() + off, raw.begin() + off + len );
+        for ( size_t i = off; i < off + len; i++ ) {
+            a = ( a + raw[i] ) % 65521u;
+            b = ( b + a ) % 65521u;
+        }
+        off += len;
+    }
+    put_be32( z, ( b << 16 ) | a );
+    FILE* f = std::fopen( filename, "wb" );
+    if ( !f ) return false;
+    static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    std::vector<unsigned char> ihdr;
+    put_be32( ihdr, w ), put_be32( ihdr, h );
+    ihdr.push_back( 8 ), ihdr.push_back( 2 ), ihdr.push_back( 0 ), ihdr.push_back( 0 ), ihdr.push_back( 0 ); // 8 bit, RGB, deflate, filter 0, no interlace
+    bool ok = std::fwrite( sig, 1, 8, f ) == 8 && write_chunk( f, "IHDR", ihdr ) && write_chunk( f, "IDAT", z ) && write_chunk( f, "IEND", {} );
+    return ( std::fclose( f ) == 0 ) && ok;
+}
+
 } // namespace mrt

@@ -381,6 +381,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     t.xforms      = s->xforms.p;
     t.out_of_tree = s->out_of_tree.p;
     t.n_nodes     = d->n_nodes;
+    t.n_records   = (uint32_t)( nodes.size() / 2 );
     t.n_out       = d->n_out_of_tree;
     t.n_xforms    = d->n_transforms;
     {

@@ -315,3 +315,87 @@ def test_device_probe_reports_the_xcd_mapping(cornell):
     if info.compute_units == 256:
         assert info.xcd_mask == 7
     dev.close()
+
+
+def test_tree_deeper_than_sixty_two_levels():
+    """The reference's SAH build has no depth limit (kdtree.cpp:392-464); the traversal stack takes
+    trees up to depth 126.  A hand-made description: 100 thin triangles side by side along x, a
+    chain of inner nodes that each split one leaf off to the left, so leaf k sits at depth k + 1."""
+    import ctypes as C
+    from raytracer_amd import abi
+    n = 100
+    rng = np.random.default_rng(5)
+    tri_p = np.zeros((n, 9), np.float32)
+    for k in range(n):
+        x0 = np.float32(k)
+        tri_p[k] = [x0 + 0.1, -1, 0, x0 + 0.9, -1, 0.2, x0 + 0.5, 1, -0.1]
+    tri_n = np.tile(np.array([0, 0, 1] * 3, np.float32), (n, 1))
+    tri_uv = np.zeros((n, 6), np.float32)
+    sphere = np.zeros((n, 4), np.float32)
+    kind = np.full(n, abi.MRT_TRIANGLE, np.uint8)
+    mat_idx = np.zeros(n, np.uint32)
+    xf_idx = np.zeros(n, np.uint32)
+    # node 0 = root; inner node i has children (2i+1: leaf i, 2i+2: the rest); the last "rest" is leaf n-1
+    nodes = np.zeros((2 * n - 1, 2), np.uint32)
+    refs = np.arange(n, dtype=np.uint32)
+    at = 0
+    for k in range(n - 1):
+        left = 2 * k + 1
+        nodes[at, 0] = np.float32(k + 1).view(np.uint32)  # split at x = k + 1
+        nodes[at, 1] = 0 | (left << 2)
+        nodes[left] = (k, 3 | (1 << 2))
+        at = left + 1
+    nodes[at] = (n - 1, 3 | (1 << 2))
+    d = abi.SceneDesc()
+    d.struct_size = C.sizeof(abi.SceneDesc)
+    d.n_objects = n
+    keep = [kind, mat_idx, xf_idx, tri_p, tri_n, tri_uv, sphere, nodes, refs]
+    d.obj_kind, d.obj_material, d.obj_transform = kind.ctypes.data_as(abi.u8p), mat_idx.ctypes.data_as(abi.u32p), xf_idx.ctypes.data_as(abi.u32p)
+    d.tri_p, d.tri_n, d.tri_uv, d.sphere = [a.ctypes.data_as(abi.f32p) for a in (tri_p, tri_n, tri_uv, sphere)]
+    ident = abi.Transform()
+    ident.m[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    ident.inv[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    d.n_transforms, d.transforms = 1, C.pointer(ident)
+    m = abi.Material()
+    m.albedo[:] = [0.5, 0.5, 0.5]
+    m.ior, m.roughness, m.metalness, m.type, m.texture = 1.0, 0.5, 0.0, 0, -1
+    d.n_materials, d.materials = 1, C.pointer(m)
+    d.n_nodes, d.nodes = len(nodes), C.cast(nodes.ctypes.data, C.POINTER(abi.KdNode))
+    d.n_refs, d.refs = n, refs.ctypes.data_as(abi.u32p)
+    d.root_min[:] = [-1, -2, -1.2]
+    d.root_max[:] = [n + 1, 2, 1.2]
+    d.env_light = -1
+    d.env_inv[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    h = C.c_void_p()
+    st = abi.hip().mrt_scene_create(C.byref(d), 0, C.byref(h))
+    assert st == abi.MRT_OK, abi.hip().mrt_last_error().decode()
+    info = abi.DeviceInfo()
+    abi.hip().mrt_scene_device_info(h, C.byref(info))
+    assert info.kd_tree_depth == n - 1
+    # rays along +x / -x through all the triangles' slabs (they defer a node at every level), and
+    # random rays
+    m_rays = 20000
+    o = np.zeros((m_rays, 3), np.float32)
+    dr = np.zeros((m_rays, 3), np.float32)
+    o[:, 0] = np.where(np.arange(m_rays) % 2 == 0, -0.5, n + 0.5)
+    o[:, 1] = rng.random(m_rays, dtype=np.float32) * 1.6 - 0.8
+    o[:, 2] = rng.random(m_rays, dtype=np.float32) * 0.6 - 0.3
+    tgt = np.stack([rng.random(m_rays, dtype=np.float32) * n, rng.random(m_rays, dtype=np.float32) * 1.6 - 0.8,
+                    rng.random(m_rays, dtype=np.float32) * 0.4 - 0.2], axis=1).astype(np.float32)
+    dr = tgt - o
+    dr = (dr / np.linalg.norm(dr, axis=1, keepdims=True)).astype(np.float32)
+    tmin, tmax = np.zeros(m_rays, np.float32), np.full(m_rays, 1e5, np.float32)
+    for any_hit in (False, True):
+        want = orc.oracle_intersect(C.pointer(d), o, dr, tmin, tmax, any_hit)
+        cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(dr[:, k]) for k in range(3)] + [tmin, tmax]
+        prim, t, u, v = np.empty(m_rays, np.int32), np.empty(m_rays, np.float32), np.empty(m_rays, np.float32), np.empty(m_rays, np.float32)
+        rays = abi.Rays(*[c.ctypes.data for c in cols])
+        hits = abi.Hits(prim.ctypes.data, t.ctypes.data, u.ctypes.data, v.ctypes.data)
+        st = abi.hip().mrt_intersect(h, m_rays, C.byref(rays), C.byref(hits), abi.MRT_ANY_HIT if any_hit else abi.MRT_CLOSEST_HIT, abi.MRT_BUF_HOST, None, None)
+        assert st == abi.MRT_OK
+        assert np.array_equal(prim, want["prim"])
+        hit = prim >= 0
+        assert hit.sum() > 2000 and len(np.unique(prim[hit])) > 60
+        assert np.array_equal(_bits(t[hit]), _bits(want["t"][hit]))
+    abi.hip().mrt_scene_destroy(h)
+    del keep

@@ -369,3 +369,62 @@ def test_host_library_under_address_and_ub_sanitizers(built):
     r = subprocess.run([exe, os.path.join(ROOT, "assets")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "host_sanitize ok" in r.stdout, r.stdout[-3000:]
     assert "ERROR: AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout and "LeakSanitizer" not in r.stdout, r.stdout[-3000:]
+
+
+def _png_decode(path):
+    """A minimal PNG reader for the files savePNG writes (8-bit RGB, filter 0): zlib does the inflate."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(typ + body) & 0xffffffff == crc, typ
+        if typ == b"IHDR":
+            w, h, depth, colour, comp, flt, lace = struct.unpack(">IIBBBBB", body)
+            assert (depth, colour, comp, flt, lace) == (8, 2, 0, 0, 0)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert not raw[:, 0].any()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+def test_png_writer(built, tmp_path):
+    """savePNG: the 8-bit conversion of the reference's saveImage (ivec3(255.f * c) clamped,
+    image.cpp:135-141) in a PNG that a standard inflate and CRC check accept; sizes that need several
+    stored deflate blocks included."""
+    rng = np.random.default_rng(8)
+    for w, h in ((5, 3), (257, 131), (640, 360)):
+        img = (rng.random((h, w, 3), dtype=np.float32) * 1.4 - 0.2).astype(np.float32)  # some values outside 0..1
+        img[0, 0] = (0.0, 1.0, 0.999999)
+        path = str(tmp_path / ("t%d.png" % w))
+        assert abi.host().mrth_save_png(path.encode(), img.ctypes.data_as(abi.f32p), w, h) == 0
+        want = np.clip((np.float32(255.0) * img).astype(np.int32), 0, 255).astype(np.uint8)
+        assert np.array_equal(_png_decode(path), want)
+    assert abi.host().mrth_save_png(b"/nonexistent-dir/x.png", img.ctypes.data_as(abi.f32p), w, h) != 0
+
+
+@pytest.mark.ref
+def test_png_writer_against_the_references_lodepng(built, tmp_path):
+    """Container only: the file savePNG writes, read back by the reference's loadPng (lodepng), has
+    the pixels of the file the reference's own saveImage writes for the same floats."""
+    lib = orc.ref()
+    rng = np.random.default_rng(9)
+    w, h = 321, 123
+    img = np.ascontiguousarray((rng.random((h, w, 3), dtype=np.float32) * 1.4 - 0.2).astype(np.float32))
+    ours = str(tmp_path / "ours.png")
+    assert abi.host().mrth_save_png(ours.encode(), img.ctypes.data_as(abi.f32p), w, h) == 0
+    lib.ref_save_image(str(tmp_path / "theirs").encode(), w, h, orc._p(img))
+    out = []
+    for path in (ours, str(tmp_path / "theirs.png")):
+        ww, hh = C.c_int(), C.c_int()
+        px = np.zeros((h, w, 3), np.float32)
+        assert lib.ref_load_png(path.encode(), C.byref(ww), C.byref(hh), orc._p(px), px.size) == 0
+        assert (ww.value, hh.value) == (w, h)
+        out.append(px)
+    assert np.array_equal(out[0], out[1])
