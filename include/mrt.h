@@ -220,7 +220,7 @@ typedef struct mrt_render_stats {
     uint64_t rays_closest; /* intersectKdTree-equivalent closest-hit queries */
     uint64_t rays_any;     /* shadow queries */
     uint64_t paths;        /* camera samples */
-    double extend_ms, shade_ms, connect_ms, generate_ms; /* device time per kernel class */
+    double extend_ms, shade_ms, connect_ms, generate_ms; /* device time per kernel class (generate_ms is 0: the first extend makes the camera rays) */
     /* with MRT_RENDER_TRACE_STATS: nodes, leaves, references and primitive tests the traversal
      * kernels actually visited for [0] continuation rays, [1] shadow rays, [2] MIS rays */
     mrt_trace_stats trace[3];

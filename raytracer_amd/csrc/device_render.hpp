@@ -1,4 +1,4 @@
-// Wavefront path tracer for gfx950: generate -> [extend -> shade -> connect]* -> accumulate.
+// Wavefront path tracer for gfx950: [extend -> shade -> connect]* -> accumulate (the first extend generates the camera rays).
 //
 // It computes what CPURenderer::run does for one camera sample (rendering/CPURenderer.cpp:46-62):
 // camera sample, SimpleCamera::get_ray, then Pathtracer::trace_ray (integrator.cpp:128-211) with
@@ -6,8 +6,8 @@
 // struct-of-arrays in HBM, indexed by the path id (pass_path below: pixels tile by tile, the
 // samples of a pixel together), so that the 64 lanes of a wave hold 64 samples of one pixel
 // (coherent rays, coalesced state access) and consecutive chunks the neighbouring pixels.  Work lists are queues of path ids; the kernels are
-//   generate        camera sample + primary ray for every id
-//   extend          closest-hit traversal of the continuation ray of every live path
+//   extend          closest-hit traversal of the continuation ray of every live path; the first
+//                   one generates the camera rays as it goes (camera sample + SimpleCamera::get_ray)
 //   shade           everything of one loop iteration of trace_ray that needs no further ray:
 //                   emission at depth 0, light choice, light sample + BSDF eval, BSDF sample for
 //                   MIS, BSDF sample for the continuation, throughput update; emits one shadow
@@ -190,27 +190,6 @@ MRT_DEV void queue_push3( uint32_t* const* queue, uint32_t* counters, const bool
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__( 256 ) generate_kernel( PathState ps, PassInfo pi, DCamera cam ) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if ( id >= pi.n_paths ) return;
-    uint32_t s_local, p_local;
-    pass_split( pi, id, s_local, p_local );
-    uint32_t x, y;
-    pass_pixel( pi, p_local, x, y );
-    const uint32_t pixel  = y * pi.width + x;
-    const uint32_t sample = pi.sample_begin + s_local;
-    const uint64_t key    = pixel_key( pi.seed, pixel );
-    // Sampler::GetCameraSample (sampler.cpp:43-49): 2D dim 0, 1D dim 0 (time, unused), 2D dim 1
-    V2 jit  = strat2d( key, 0, sample, pi.spp_x, pi.spp_y );
-    V2 lens = strat2d( key, 1, sample, pi.spp_x, pi.spp_y );
-    V3 o, d;
-    camera_ray( cam, (float)x + jit.x, (float)y + jit.y, lens.x, lens.y, o, d );
-    // throughput 1, radiance 0, no pending term and the start of the engine stream are what the
-    // first shade of a path assumes without reading them
-    put_ray( ps.ray0, ps.ray1, id, o, d, 100000.f );
-}
-
-// ------------------------------------------------------------------------------------------------
 // extend: closest hit of the continuation rays.  `queue` == nullptr means the identity queue.
 struct ExtendIO {
     PathState ps;
@@ -222,6 +201,42 @@ struct ExtendIO {
     }
     MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
 };
+
+// The first bounce makes its camera rays itself: the ray of path i -- Sampler::GetCameraSample
+// (sampler.cpp:43-49: 2D dimension 0, 1D dimension 0 = time, unused, 2D dimension 1) and
+// SimpleCamera::get_ray -- is computed when a lane takes it, stored for shade, and traced.  There
+// is no generate pass and no reading back of what it would have written (+1.2 % on the frame).
+// Throughput 1, radiance 0, no pending term and the start of the engine stream are what the first
+// shade of a path assumes without reading them.
+struct CameraIO {
+    PathState ps;
+    PassInfo pi;
+    DCamera cam;
+    MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
+        id = i;
+        uint32_t s_local, p_local;
+        pass_split( pi, id, s_local, p_local );
+        uint32_t x, y;
+        pass_pixel( pi, p_local, x, y );
+        const uint32_t pixel  = y * pi.width + x;
+        const uint32_t sample = pi.sample_begin + s_local;
+        const uint64_t key    = pixel_key( pi.seed, pixel );
+        V2 jit  = strat2d( key, 0, sample, pi.spp_x, pi.spp_y );
+        V2 lens = strat2d( key, 1, sample, pi.spp_x, pi.spp_y );
+        camera_ray( cam, (float)x + jit.x, (float)y + jit.y, lens.x, lens.y, o, d );
+        t0 = 0.f, t1 = 100000.f;
+        put_ray( ps.ray0, ps.ray1, id, o, d, t1 );
+    }
+    MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
+};
+template <bool STATS>
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_camera_kernel( DTrace tr, CameraIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];
+    lds_u32* lp = (lds_u32*)lds;
+    DStats st { 0, 0, 0, 0 };
+    trace_stream<false, false, STATS>( tr, lp, io, n, deal, st );
+    if ( STATS ) flush_stats( st, stats );
+}
 
 // STATS (all traversal kernels of this file): also count the visited nodes, leaves, references
 // and primitive tests into stats[0..3].

@@ -13,6 +13,8 @@ from collections import defaultdict
 
 def short(name):
     name = name.split("(")[0]
+    if "extend_camera_kernel" in name:  # the first-bounce instance of the extend traversal
+        return "extend_kernel"
     for k in ("extend_batch_kernel", "extend_kernel", "connect_shadow_kernel", "connect_mis_occlusion_kernel", "connect_mis_kernel", "mis_resolve_kernel", "shade_kernel",
               "generate_kernel", "accumulate_kernel", "resolve_kernel"):
         if k in name:
