@@ -90,7 +90,7 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
     sc = getattr(scenes, name)(WIDTH, HEIGHT)
     tree = sc.initKdTree()
     build_s = time.time() - t0
-    flat = tree.flatten(1)
+    flat = tree.flatten(int(os.environ.get("MRT_LAYOUT", "1")))
     dev = DeviceScene(flat, device=local_rank)
     n_nodes, n_refs, depth = tree.counts()
 
