@@ -209,11 +209,14 @@ typedef struct mrt_render_params {
 
 enum {
     MRT_RENDER_TRACE_STATS = 1, /* count the traversal work of the call into mrt_render_stats.trace (slower kernels) */
-    MRT_RENDER_SERIAL      = 2  /* one kernel at a time on the caller's stream.  By default the three ray lists a
+    MRT_RENDER_SERIAL      = 2, /* one kernel at a time on the caller's stream.  By default the three ray lists a
                                    bounce leaves (shadow, MIS, continuation) are traced side by side on the handle's
                                    internal streams, forked from and joined to the caller's stream with events; the
                                    per-class device times of mrt_render_stats then overlap.  Serial runs give the
                                    time of each kernel alone. */
+    MRT_RENDER_NO_KIND_BUCKETS = 4 /* in a scene whose materials are of more than one kind (plain, textured,
+                                   transparent) the shade kernel regroups the paths of a block by kind from the
+                                   second bounce on; this flag turns that off (measurements) */
 };
 
 typedef struct mrt_render_stats {

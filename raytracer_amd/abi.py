@@ -19,6 +19,7 @@ MRT_BUF_HOST, MRT_BUF_DEVICE = 0, 1
 MRT_CLOSEST_HIT, MRT_ANY_HIT = 0, 1
 MRT_RENDER_TRACE_STATS = 1
 MRT_RENDER_SERIAL = 2
+MRT_RENDER_NO_KIND_BUCKETS = 4
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)

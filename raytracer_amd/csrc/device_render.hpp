@@ -265,6 +265,51 @@ MRT_DEV void fold_pending( PathState& ps, uint32_t id, V3& L ) {
     ps.pending[id] = 0;
 }
 
+// Regroups the paths of a shade block by kind.  In: this thread's path (`have`: it has one).  Out:
+// the path this thread is to shade instead (return value: it has one).  The block's paths are
+// partitioned, order kept within a kind, into miss / plain / textured / transparent, and thread t
+// takes the t-th of them.  Every thread of the block must call this.
+MRT_DEV bool bucket_by_kind( const DTrace& tr, const PathState& ps, uint32_t& id, bool have ) {
+    __shared__ uint32_t s_ids[MRT_SHADE_BLOCK];
+    __shared__ uint32_t s_cnt[4][MRT_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_total;
+    uint32_t kind = 4u; // no path
+    if ( have ) {
+        const uint32_t bits = __float_as_uint( ps.hit[id].x );
+        if ( bits == 0xffffffffu ) kind = 0u;
+        else {
+            const uint32_t flags = __float_as_uint( tr.prims[MRT_PRIM_Q * (size_t)( bits & 0x7fffffffu )].w );
+            kind                 = 1u + ( ( flags >> MRT_PRIM_SHADE_SHIFT ) & 3u );
+            if ( kind > 3u ) kind = 3u;
+        }
+    }
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    unsigned long long mine = 0;
+    for ( uint32_t k = 0; k < 4u; k++ ) {
+        const unsigned long long m = __ballot( kind == k );
+        if ( kind == k ) mine = m;
+        if ( lane == 0 ) s_cnt[k][wave] = (uint32_t)__popcll( m );
+    }
+    __syncthreads();
+    if ( threadIdx.x == 0 ) {
+        uint32_t sum = 0;
+        for ( uint32_t k = 0; k < 4u; k++ )
+            for ( uint32_t w = 0; w < n_waves; w++ ) {
+                const uint32_t c = s_cnt[k][w];
+                s_cnt[k][w]      = sum;
+                sum += c;
+            }
+        s_total = sum;
+    }
+    __syncthreads();
+    if ( kind < 4u ) s_ids[s_cnt[kind][wave] + (uint32_t)__popcll( mine & ( ( 1ull << lane ) - 1ull ) )] = id;
+    __syncthreads();
+    const bool out = threadIdx.x < s_total;
+    if ( out ) id = s_ids[threadIdx.x];
+    __syncthreads(); // the arrays are reused by the block's next run
+    return out;
+}
+
 // One loop iteration of trace_ray for every live path of the bounce.
 // `chunks` == nullptr: one block per MRT_SHADE_BLOCK paths (the first bounce, whose path count the
 // host knows).  Otherwise the grid is sized for the chip and its blocks draw runs of
@@ -278,7 +323,11 @@ MRT_DEV void fold_pending( PathState& ps, uint32_t id, V3& L ) {
 // connect_mis_occlusion adds it for the rays that escape (no mis_resolve pass; a MIS ray whose
 // contribution would be black is not traced at all).
 // FIRST: the first bounce (depth 0, identity queue, one block per MRT_SHADE_BLOCK paths).
-template <bool MIS_ESCAPE, bool FIRST>
+// BUCKET (later bounces of a scene whose materials are of more than one shade kind): the paths a
+// block draws are regrouped by what shade will do with them -- miss, plain, textured, transparent
+// (bucket_by_kind) -- so that the lanes of a wave run the same branch of the material code.  In the
+// first bounce a wave holds 64 samples of one pixel, which hit one material anyway.
+template <bool MIS_ESCAPE, bool FIRST, bool BUCKET = false>
 __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kernel( DTrace tr, DShade sh, PathState ps, PassInfo pi, Queues q, const uint32_t* __restrict__ queue_, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t depth_, uint32_t* __restrict__ chunks_ ) {
     const uint32_t depth           = FIRST ? 0u : depth_;
     const uint32_t* const queue    = FIRST ? nullptr : queue_;
@@ -299,8 +348,10 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
     const uint32_t i = base + threadIdx.x;
     bool alive = false, has_shadow = false, has_mis = false;
     uint32_t id = 0;
-    if ( i < n ) {
-        id = queue ? queue[i] : i;
+    bool have   = i < n;
+    if ( have ) id = queue ? queue[i] : i;
+    if ( BUCKET ) have = bucket_by_kind( tr, ps, id, have );
+    if ( have ) {
         // a path's first shade starts from radiance 0, throughput 1 and nothing pending
         V3 L = mk3( 0.f ), tp = mk3( 1.f );
         if ( depth != 0 ) {

@@ -52,7 +52,7 @@
 //   q0 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane),
 //   q1 = e1.xyz , e2.x              bit 2 emission != (0,0,0) component-wise (kdtree.cpp:533-534),
 //   q2 = e2.yz  , material , 0      bit 3 emission.r+g+b != 0 (isBlack, integrator.cpp:110),
-//                                   bits 4.. transform index (0 = identity)
+//                                   bits 4-5 shade kind of the object's material, bits 6.. transform index (0 = identity)
 //   e1 = p2 - p1, e2 = p3 - p1 (fp32, as triangle.cpp:9-10)
 // Device tree: 32-byte records, one per node of even depth (the root has depth 0), holding that
 // node and its two children, so one fetch serves two levels of the descent:
@@ -70,7 +70,11 @@
 #define MRT_PRIM_PLANE 2u
 #define MRT_PRIM_EMISSIVE 4u
 #define MRT_PRIM_EMISSIVE_SUM 8u
-#define MRT_PRIM_XF_SHIFT 4
+#define MRT_PRIM_SHADE_SHIFT 4 // bits 4-5: what shade does with a hit on the object (MRT_SHADE_*)
+#define MRT_SHADE_PLAIN 0u        //   Cook-Torrance, constant albedo
+#define MRT_SHADE_TEXTURED 1u     //   Cook-Torrance, albedo from a texture
+#define MRT_SHADE_TRANSPARENT 2u  //   smooth dielectric
+#define MRT_PRIM_XF_SHIFT 6
 
 struct DTrace {
     const uint4* nodes; // two uint4 per record

@@ -100,6 +100,7 @@ struct mrt_scene {
     uint32_t tree_depth = 0;
     int n_cus           = 256;
     bool no_emitters    = false; // no object has a material with a non-zero emission component
+    bool mixed_kinds    = false; // the objects' materials are of more than one shade kind (plain / textured / transparent)
     bool has_camera     = false;
     ~mrt_scene();
 };
@@ -321,6 +322,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     }
 
     bool no_emitters = true;
+    uint32_t kinds_seen = 0; // bit k: some object's material is of shade kind k
     std::vector<float4> prims( MRT_PRIM_Q * (size_t)d->n_objects, make_float4( 0.f, 0.f, 0.f, 0.f ) );
     for ( uint32_t i = 0; i < d->n_objects; i++ ) {
         uint32_t kind = d->obj_kind[i], mat = d->obj_material[i], xf = d->obj_transform[i];
@@ -336,7 +338,10 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         uint32_t emissive = !( e[0] == 0.f && e[1] == 0.f && e[2] == 0.f );
         uint32_t em_sum   = !( e[0] + e[1] + e[2] == 0.f );
         if ( emissive || em_sum ) no_emitters = false;
-        uint32_t flags    = k | ( emissive ? MRT_PRIM_EMISSIVE : 0u ) | ( em_sum ? MRT_PRIM_EMISSIVE_SUM : 0u ) | ( xf << MRT_PRIM_XF_SHIFT );
+        const mrt_material& mm = d->materials[mat];
+        const uint32_t shade_kind = mm.type == MRT_MAT_TRANSPARENT ? MRT_SHADE_TRANSPARENT : ( mm.texture >= 0 ? MRT_SHADE_TEXTURED : MRT_SHADE_PLAIN );
+        kinds_seen |= 1u << shade_kind;
+        uint32_t flags    = k | ( emissive ? MRT_PRIM_EMISSIVE : 0u ) | ( em_sum ? MRT_PRIM_EMISSIVE_SUM : 0u ) | ( shade_kind << MRT_PRIM_SHADE_SHIFT ) | ( xf << MRT_PRIM_XF_SHIFT );
         const float* p    = d->tri_p + 9 * (size_t)i;
         float fl, fm;
         std::memcpy( &fl, &flags, 4 );
@@ -360,6 +365,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     s->tree_depth = depth;
     s->n_cus      = n_cus > 0 ? n_cus : 256;
     s->no_emitters = no_emitters;
+    s->mixed_kinds = ( kinds_seen & ( kinds_seen - 1u ) ) != 0u;
     HIP_TRY( s->nodes.upload( nodes ) );
     HIP_TRY( s->refs.upload( std::vector<uint32_t>( d->refs, d->refs + d->n_refs ) ) );
     HIP_TRY( s->prims.upload( prims ) );

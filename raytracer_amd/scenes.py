@@ -79,6 +79,25 @@ def bunny_pair(width=1920, height=1080, env="brown_photostudio_06_1k.hdr", subdi
     return sc
 
 
+def mixed_kinds(width=1920, height=1080, env="brown_photostudio_06_1k.hdr"):
+    """bunny_pair with all three kinds of material the shade kernel distinguishes: a glass bunny
+    (TRANSPARENT), a diffuse one (plain Cook-Torrance) and a checker-textured floor."""
+    sc = Scene()
+    frm, at = (0.0, 2.8, 7.5), (0.0, 2.0, 0.0)
+    focus = float(np.linalg.norm(np.array(at, np.float32) - np.array(frm, np.float32)).astype(np.float32))
+    sc.setSimpleCamera(frm, at, (0, 1, 0), 60, width, height, 0.02, focus)
+    if env:
+        sc.add_ibl_file(asset(env), also_env=True)
+    floor = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(0.6, 0.6, 0.6), metalness=0.0, roughness=0.8)
+    sc.set_checker(floor, (0.8, 0.8, 0.8), (0.15, 0.15, 0.25), Transform().scale(0.05, 0.05, 1))
+    sc.add_plane(Transform().scale(10, 10, 1).rotate((-1, 0, 0), 90).translate((0, 0.66, 0)), floor)
+    diffuse = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(0, 1, 0), roughness=0.5, metalness=0.1)
+    glass = sc.CreateMaterial(abi.MRT_MAT_TRANSPARENT, albedo=(1, 1, 1), ior=1.5, roughness=0.01)
+    sc.addObjectsFromFile(asset("stanford-bunny.obj"), diffuse, Transform().translate((-1.5, 0.0, 0)), prescale=20.0)
+    sc.addObjectsFromFile(asset("stanford-bunny.obj"), glass, Transform().translate((2.1, 0.0, 0)), prescale=20.0)
+    return sc
+
+
 def million_bunny(width=1920, height=1080, env="brown_photostudio_06_1k.hdr"):
     """BASELINE config 3 size class (the reference's dragon.obj is not available): the stanford
     bunny subdivided twice, 1 111 216 triangles.  Everything is four times the size of bunny_ibl so

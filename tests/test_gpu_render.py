@@ -507,3 +507,24 @@ def test_overlapped_and_serial_execution_give_the_same_frame(scene):
     cpu, crs, _, _ = orc.oracle_render(flat.desc, render_params(96, 96, 4, 4, max_depth=5, seed=13), 0, threads=16)
     check_images(frames[0][0], cpu, 16)
     dev.close()
+
+
+def test_kind_buckets_do_not_change_the_frame():
+    """In a scene with plain, textured and transparent materials the shade kernel regroups the paths
+    of a block by kind from the second bounce on; MRT_RENDER_NO_KIND_BUCKETS turns that off.  Every
+    path computes the same either way: identical bits, and parity with the oracle."""
+    import torch
+    sc = scenes.mixed_kinds(160, 96, env=None)
+    sc.add_ibl_pixels(scenes.synthetic_env())
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    frames = []
+    for flags in (0, abi.MRT_RENDER_NO_KIND_BUCKETS):
+        img = torch.zeros((96, 160, 3), dtype=torch.float32, device="cuda")
+        rs = dev.render(render_params(160, 96, 3, 3, max_depth=8, seed=4, flags=flags), img)
+        torch.cuda.synchronize()
+        frames.append((img.cpu().numpy(), rs.rays_closest, rs.rays_any))
+    assert np.array_equal(frames[0][0], frames[1][0]) and frames[0][1:] == frames[1][1:]
+    cpu, crs, _, _ = orc.oracle_render(flat.desc, render_params(160, 96, 3, 3, max_depth=8, seed=4), 0, threads=16)
+    check_images(frames[0][0], cpu, 9)
+    dev.close()
