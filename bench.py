@@ -88,7 +88,8 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
 
     t0 = time.time()
     sc = getattr(scenes, name)(WIDTH, HEIGHT)
-    tree = sc.initKdTree()
+    # torchrun sets OMP_NUM_THREADS=1 for its workers: give the tree build its share of the host explicitly
+    tree = sc.initKdTree(max(1, min(16, (os.cpu_count() or 1) // max(world, 1))))
     build_s = time.time() - t0
     flat = tree.flatten(int(os.environ.get("MRT_LAYOUT", "1")))
     dev = DeviceScene(flat, device=local_rank)
