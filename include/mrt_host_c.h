@@ -87,6 +87,11 @@ int mrth_hip_render_progressive( void* scene, uint32_t w, uint32_t h, int spp_x,
                                  int checkpoint_after, const char* checkpoint_path, float* rgb_sum, mrt_render_stats* stats );
 /* savePNG: linear or gamma-encoded floats [h][w][3] -> 8-bit RGB PNG as saveImage writes it (image.cpp:127-146). */
 int mrth_save_png( const char* filename, const float* rgb, uint32_t w, uint32_t h );
+/* image_texture(filename) (textures.hpp:50-62): a PNG (any colour type, bit depth, interlacing) or a
+ * binary PPM; texels = byte / 255.f as loadPng makes them (image.cpp:30-34).  mrth_load_image copies
+ * them to rgb when capacity_floats >= w * h * 3 (w, h are always written). */
+int mrth_load_image( const char* filename, uint32_t* w, uint32_t* h, float* rgb, uint64_t capacity_floats );
+int mrth_material_set_image_file( void* scene, int id, const char* filename, void* tex_xf );
 int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, float* rgb_sum, mrt_render_stats* stats, double* seconds );
 /* The same with HIPRenderer::devices: the samples are divided among the listed devices (a device
  * may be listed more than once: one handle, with its own workspace, per entry). */

@@ -82,4 +82,8 @@ inline mat3 zero3() {
     return r;
 }
 
+// png_read.cpp: r, g, b bytes of every pixel as lodepng::decode's default RGBA8 output holds them
+bool decode_png_rgb8( const unsigned char* file, size_t size, uint32_t& w, uint32_t& h, std::vector<unsigned char>& rgb );
+bool load_png_rgb8( const char* filename, uint32_t& w, uint32_t& h, std::vector<unsigned char>& rgb );
+
 } // namespace mrt

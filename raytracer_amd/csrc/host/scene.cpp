@@ -185,21 +185,34 @@ texture* checker_texture( color3 c1, color3 c2 ) {
     t->odd  = c2;
     return t;
 }
-// Binary PPM (P6, maxval 255) reader; the value mapping is loadPng's, byte / 255.f (image.cpp:30-34).
+// image_texture( filename ) (textures.hpp:50-62 -> loadPng, image.cpp:13-40): a PNG file, or a
+// binary PPM (P6, maxval 255) holding the same bytes.  The value mapping is loadPng's, byte / 255.f.
 texture* image_texture( const char* filename ) {
     FILE* f = std::fopen( filename, "rb" );
     if ( !f ) return nullptr;
-    char magic[3] = { 0 };
-    int w = 0, h = 0, maxv = 0;
-    if ( std::fscanf( f, "%2s %d %d %d", magic, &w, &h, &maxv ) != 4 || std::strcmp( magic, "P6" ) != 0 || maxv != 255 ) {
+    unsigned char sig[2] = { 0, 0 };
+    size_t n_sig         = std::fread( sig, 1, 2, f );
+    std::rewind( f );
+    uint32_t w = 0, h = 0;
+    std::vector<unsigned char> buf;
+    if ( n_sig == 2 && sig[0] == 0x89 && sig[1] == 'P' ) {
         std::fclose( f );
-        return nullptr;
+        if ( !load_png_rgb8( filename, w, h, buf ) ) return nullptr;
     }
-    std::fgetc( f );
-    std::vector<unsigned char> buf( (size_t)w * h * 3 );
-    size_t got = std::fread( buf.data(), 1, buf.size(), f );
-    std::fclose( f );
-    if ( got != buf.size() ) return nullptr;
+    else {
+        char magic[3] = { 0 };
+        int pw = 0, ph = 0, maxv = 0;
+        if ( std::fscanf( f, "%2s %d %d %d", magic, &pw, &ph, &maxv ) != 4 || std::strcmp( magic, "P6" ) != 0 || maxv != 255 || pw <= 0 || ph <= 0 ) {
+            std::fclose( f );
+            return nullptr;
+        }
+        std::fgetc( f );
+        w = (uint32_t)pw, h = (uint32_t)ph;
+        buf.resize( (size_t)w * h * 3 );
+        size_t got = std::fread( buf.data(), 1, buf.size(), f );
+        std::fclose( f );
+        if ( got != buf.size() ) return nullptr;
+    }
     auto* t   = new texture;
     t->kind   = MRT_TEX_IMAGE;
     t->width  = w;

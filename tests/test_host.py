@@ -428,3 +428,155 @@ def test_png_writer_against_the_references_lodepng(built, tmp_path):
         assert (ww.value, hh.value) == (w, h)
         out.append(px)
     assert np.array_equal(out[0], out[1])
+
+
+def _png_encode(path, px, colour, depth, palette=None, interlace=False, filters=(0, 1, 2, 3, 4), level=6, idat_split=0):
+    """Writes samples px[h][w][channels] (integers below 2^depth) as a PNG with the given colour
+    type, cycling through `filters` by scanline."""
+    import struct
+    import zlib
+    h, w, ch = px.shape
+
+    def pack_rows(img):
+        hh, ww, _ = img.shape
+        if depth == 16:
+            rows = img.astype(">u2").reshape(hh, -1).view(np.uint8)
+        elif depth == 8:
+            rows = img.astype(np.uint8).reshape(hh, -1)
+        else:
+            per = 8 // depth
+            flat = img.reshape(hh, ww).astype(np.uint8)
+            pad = (-ww) % per
+            flat = np.pad(flat, ((0, 0), (0, pad)))
+            rows = np.zeros((hh, flat.shape[1] // per), np.uint8)
+            for k in range(per):
+                rows |= flat[:, k::per] << (8 - depth * (k + 1))
+        return rows
+
+    def filtered(rows, bpp):
+        out = bytearray()
+        prev = np.zeros(rows.shape[1], np.int32)
+        for y in range(rows.shape[0]):
+            cur = rows[y].astype(np.int32)
+            a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if rows.shape[1] > bpp else np.zeros_like(cur)
+            c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if rows.shape[1] > bpp else np.zeros_like(cur)
+            f = filters[y % len(filters)]
+            if f == 0:
+                line = cur
+            elif f == 1:
+                line = cur - a
+            elif f == 2:
+                line = cur - prev
+            elif f == 3:
+                line = cur - ((a + prev) >> 1)
+            else:
+                p = a + prev - c
+                pa, pb, pc = abs(p - a), abs(p - prev), abs(p - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+                line = cur - pred
+            out.append(f)
+            out += (line & 255).astype(np.uint8).tobytes()
+            prev = cur
+        return bytes(out)
+
+    bpp = max(1, ch * depth // 8)
+    if interlace:
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = px[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filtered(pack_rows(sub), bpp)
+    else:
+        raw = filtered(pack_rows(px), bpp)
+    z = zlib.compress(raw, level)
+
+    def chunk(typ, body):
+        return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xffffffff)
+
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, 1 if interlace else 0))
+    data += chunk(b"gAMA", struct.pack(">I", 45455))
+    if palette is not None:
+        data += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    if idat_split:
+        for i in range(0, len(z), idat_split):
+            data += chunk(b"IDAT", z[i:i + idat_split])
+    else:
+        data += chunk(b"IDAT", z)
+    data += chunk(b"IEND", b"")
+    open(path, "wb").write(data)
+
+
+def _png_cases(tmp_path):
+    """(path, expected r, g, b bytes [h][w][3]) for every colour type / bit depth, interlaced or not."""
+    rng = np.random.default_rng(21)
+    out = []
+    for colour, ch, depths in ((0, 1, (1, 2, 4, 8, 16)), (2, 3, (8, 16)), (3, 1, (1, 2, 4, 8)), (4, 2, (8, 16)), (6, 4, (8, 16))):
+        for depth in depths:
+            for interlace in (False, True):
+                for w, h in ((1, 1), (7, 5), (33, 17)):
+                    px = rng.integers(0, 1 << depth, (h, w, ch))
+                    palette = rng.integers(0, 256, (1 << depth, 3)) if colour == 3 else None
+                    s8 = (px >> 8) if depth == 16 else px  # lodepng keeps the high byte of 16-bit samples
+                    if colour == 3:
+                        want = palette[px[:, :, 0]]
+                    elif colour in (0, 4):
+                        g = s8[:, :, 0] if depth >= 8 else (px[:, :, 0] * 255) // ((1 << depth) - 1)
+                        want = np.stack([g, g, g], axis=-1)
+                    else:
+                        want = s8[:, :, :3]
+                    path = str(tmp_path / ("c%d_d%d_i%d_%dx%d.png" % (colour, depth, interlace, w, h)))
+                    _png_encode(path, px, colour, depth, palette, interlace, level=(0 if w == 7 else 9 if w == 1 else 6), idat_split=(97 if w == 33 else 0))
+                    out.append((path, want.astype(np.uint8)))
+    # a picture large enough for long matches, several deflate blocks and every filter on real content
+    yy, xx = np.mgrid[0:301, 0:517]
+    big = np.stack([(xx * 3 + yy) & 255, (xx ^ yy) & 255, ((xx * yy) >> 3) & 255], axis=-1)
+    big[100:200, 50:400] = (200, 30, 77)
+    path = str(tmp_path / "big.png")
+    _png_encode(path, big, 2, 8)
+    out.append((path, big.astype(np.uint8)))
+    return out
+
+
+def _load_image(path):
+    w, h = C.c_uint32(), C.c_uint32()
+    if abi.host().mrth_load_image(path.encode(), C.byref(w), C.byref(h), None, 0) != 0:
+        return None
+    px = np.zeros((h.value, w.value, 3), np.float32)
+    assert abi.host().mrth_load_image(path.encode(), C.byref(w), C.byref(h), px.ctypes.data_as(abi.f32p), px.size) == 0
+    return px
+
+
+def test_png_reader_all_formats(built, tmp_path):
+    """image_texture on PNG files of every colour type and bit depth, plain and Adam7-interlaced,
+    all five scanline filters, stored / fixed / dynamic deflate blocks, IDAT split over many chunks:
+    texels = (byte of lodepng's RGBA8 conversion) / 255.f (image.cpp:30-34)."""
+    for path, want in _png_cases(tmp_path):
+        got = _load_image(path)
+        assert got is not None, path
+        assert np.array_equal(got, want.astype(np.float32) / np.float32(255.0)), path
+    # damaged files are refused, not half-read
+    data = open(path, "rb").read()
+    for bad in (data[:len(data) // 2], data[:8] + b"\0" * 40, b"P6 2 2"):
+        p = str(tmp_path / "bad.png")
+        open(p, "wb").write(bad)
+        assert _load_image(p) is None
+    assert _load_image(str(tmp_path / "missing.png")) is None
+
+
+@pytest.mark.ref
+def test_png_reader_against_the_references_lodepng(built, tmp_path):
+    """Container only: image_texture's texels equal what the reference's loadPng (lodepng::decode,
+    image.cpp:13-40) returns, on the generated files of every format and on the reference's own
+    texture files."""
+    lib = orc.ref()
+    import glob
+    paths = [p for p, _ in _png_cases(tmp_path)]
+    paths += sorted(glob.glob("/root/reference/assets/*.png"))[:6] + ["/root/reference/assets/pf-s125-ake7011-a.png", "/root/reference/assets/container2.png"]
+    for path in paths:
+        got = _load_image(path)
+        assert got is not None, path
+        ww, hh = C.c_int(), C.c_int()
+        px = np.zeros_like(got)
+        assert lib.ref_load_png(path.encode(), C.byref(ww), C.byref(hh), orc._p(px), px.size) == 0, path
+        assert (hh.value, ww.value) == got.shape[:2]
+        assert np.array_equal(got, px), path
