@@ -29,6 +29,10 @@ void mrth_transform_get( void* xf, mrt_transform* out );
 /* initScene / freeScene / Scene::CreateMaterial (scene.h:33-37, scene.cpp:130-139) */
 void* mrth_scene_new( void );
 void mrth_scene_free( void* scene );
+/* parseScene(sceneId) (example_scenes.cpp:1594-1647) over the scene data files of asset_dir/scenes/
+ * (null asset_dir: $MRT_ASSETS, else "../assets"); loadSceneFile for one file.  Null on failure. */
+void* mrth_parse_scene( int scene_id, int width, int height, const char* asset_dir );
+void* mrth_load_scene_file( const char* filename, int width, int height, const char* asset_dir );
 int mrth_create_material( void* scene, int mat_type );
 int mrth_material_set( void* scene, int id, const mrt_material* m ); /* texture field ignored */
 int mrth_material_get( void* scene, int id, mrt_material* m );

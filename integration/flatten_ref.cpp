@@ -3,12 +3,31 @@
 
 #include "../Camera.h"
 #include "../Object.h"
+#include "../image.h"
 
 #include <cstring>
 #include <map>
 #include <stdexcept>
 
 namespace {
+
+// image_texture keeps its RenderImage in a private member (textures.hpp:123-124) and offers no
+// accessor, and scene 18 -- the one main.cpp renders -- attaches one (example_scenes.cpp:1244).  To
+// leave the reference's headers untouched, the member is reached through an explicit template
+// instantiation, which the language exempts from access checking ([temp.spec]/6); a maintainer who
+// prefers a one-line accessor in image_texture can replace imageOf() by it.
+template <class Tag, typename Tag::type Member>
+struct PrivateMember {
+    friend typename Tag::type memberPointer( Tag ) { return Member; }
+};
+struct ImageTextureImage {
+    typedef RenderImage* image_texture::*type;
+    friend type memberPointer( ImageTextureImage );
+};
+template struct PrivateMember<ImageTextureImage, &image_texture::m_image>;
+const RenderImage* imageOf( const image_texture* t ) {
+    return t->*memberPointer( ImageTextureImage() );
+}
 
 void put3( float* d, const vec3& v ) {
     d[0] = v.x, d[1] = v.y, d[2] = v.z;
@@ -137,19 +156,26 @@ void mrtFlattenGeometry( Scene* scene, KdTree* tree, MrtFlat& out ) {
             auto it = texIndex.find( m.m_texture );
             if ( it == texIndex.end() ) {
                 mrt_texture t {};
+                t.texel_offset = out.texels.size(); // where an image's texels start; unused by a checker
                 if ( auto* chk = dynamic_cast<const checker_texture*>( m.m_texture ) ) {
                     // the two solid colours, read through the public interface
                     t.kind = MRT_TEX_CHECKER;
                     put3( t.even, chk->even->value( 0.f, 0.f ) );
                     put3( t.odd, chk->odd->value( 0.f, 0.f ) );
                 }
-                else {
-                    // image_texture keeps its RenderImage private (textures.hpp:123-124): flattening
-                    // one needs an accessor added there (width, height, data -> texels as float RGB
-                    // rows, kind MRT_TEX_IMAGE).  No live reference scene attaches one
-                    // (example_scenes.cpp:111 is commented out).
-                    throw std::runtime_error( "flatten: only checker_texture can be read through the reference's public interface" );
+                else if ( auto* img = dynamic_cast<const image_texture*>( m.m_texture ) ) {
+                    const RenderImage* px = imageOf( img );
+                    if ( !px ) throw std::runtime_error( "flatten: an image_texture whose file could not be loaded" ); // loadPng returned nullptr
+                    t.kind         = MRT_TEX_IMAGE;
+                    t.width        = (uint32_t)px->width;
+                    t.height       = (uint32_t)px->height;
+                    for ( size_t k = 0; k < px->width * px->height; k++ ) {
+                        out.texels.push_back( px->data[k].x );
+                        out.texels.push_back( px->data[k].y );
+                        out.texels.push_back( px->data[k].z );
+                    }
                 }
+                else { throw std::runtime_error( "flatten: only checker_texture and image_texture are supported by the GPU backend" ); }
                 t.xf = toAbi( m.m_texture->m_transform );
                 it   = texIndex.emplace( m.m_texture, (int32_t)out.textures.size() ).first;
                 out.textures.push_back( t );

@@ -3,7 +3,7 @@
 // is meant to be dropped into the reference tree as src/rendering/flatten_ref.{h,cpp} and built
 // with it (it uses glm and the reference's types, nothing of this repository but mrt.h).
 //
-//   mrtFlattenGeometry   objects, transforms, materials, checker textures, kd-tree, camera
+//   mrtFlattenGeometry   objects, transforms, materials, checker and image textures, kd-tree, camera
 //                        (needs scene.h, kdtree.h, Camera.h, Object.h only)
 //   mrtFlattenLights     Scene::lights / envLights (flatten_ref_lights.cpp: needs Light.h)
 #pragma once
@@ -33,6 +33,6 @@ struct MrtFlat {
 };
 
 // Throws std::runtime_error on a scene the backend cannot represent (cube objects, materials with a
-// texture kind other than checker_texture, a camera that is not a SimpleCamera).
+// texture kind other than checker_texture and image_texture, a camera that is not a SimpleCamera).
 void mrtFlattenGeometry( Scene* scene, KdTree* tree, MrtFlat& out );
 void mrtFlattenLights( Scene* scene, MrtFlat& out );

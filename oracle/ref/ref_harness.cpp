@@ -722,6 +722,14 @@ void ref_material_set_checker( void* scene_, int mat, const float* even3, const 
     scene->m_Materials[mat].m_texture  = tex;
     scene->m_Materials[mat].m_MatModel = MaterialModel::COOK_TORRANCE;
 }
+// An image_texture of a PNG file on material `mat` (what example_scenes.cpp:1244 does)
+void ref_material_set_image( void* scene_, int mat, const char* png_path, void* xf ) {
+    auto* scene = static_cast<Scene*>( scene_ );
+    auto* tex   = new image_texture( png_path );
+    if ( xf ) tex->m_transform = *static_cast<Transform*>( xf );
+    scene->m_Materials[mat].m_texture  = tex;
+    scene->m_Materials[mat].m_MatModel = MaterialModel::COOK_TORRANCE;
+}
 
 // ---------------------------------------------------------------- image.cpp
 // loadPng (image.cpp:14-41) of a file: width, height and the float pixels (byte / 255).

@@ -192,6 +192,8 @@ def host():
             "mrth_hip_render": (ci, [vp, C.c_uint32, C.c_uint32, ci, ci, ci, C.c_uint32, ci, f32p,
                                      C.POINTER(RenderStats), C.POINTER(C.c_double)]),
             "mrth_save_png": (ci, [C.c_char_p, f32p, C.c_uint32, C.c_uint32]),
+            "mrth_parse_scene": (vp, [ci, ci, ci, C.c_char_p]),
+            "mrth_load_scene_file": (vp, [C.c_char_p, ci, ci, C.c_char_p]),
             "mrth_load_image": (ci, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), f32p, C.c_uint64]),
             "mrth_material_set_image_file": (ci, [vp, ci, C.c_char_p, vp]),
             "mrth_hip_render_devices": (ci, [vp, C.c_uint32, C.c_uint32, ci, ci, ci, C.c_uint32, C.POINTER(C.c_int), ci, f32p,

@@ -116,6 +116,23 @@ void* mrth_scene_new( void ) {
 void mrth_scene_free( void* scene ) {
     freeScene( static_cast<Scene*>( scene ) );
 }
+// parseScene( id ) / loadSceneFile( path ): null on failure (mrth_last_error says why)
+void* mrth_parse_scene( int scene_id, int width, int height, const char* asset_dir ) {
+    void* out = nullptr;
+    guarded( [&] {
+        out = parseScene( scene_id, width, height, asset_dir );
+        return 0;
+    } );
+    return out;
+}
+void* mrth_load_scene_file( const char* filename, int width, int height, const char* asset_dir ) {
+    void* out = nullptr;
+    guarded( [&] {
+        out = loadSceneFile( filename, width, height, asset_dir );
+        return 0;
+    } );
+    return out;
+}
 int mrth_create_material( void* scene, int mat_type ) {
     return (int)static_cast<Scene*>( scene )->CreateMaterial( MaterialModel::COOK_TORRANCE, (MatType)mat_type ).m_UID;
 }

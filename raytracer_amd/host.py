@@ -60,9 +60,26 @@ class Transform:
 class Scene:
     """initScene() ... freeScene()."""
 
-    def __init__(self):
-        self._h = abi.host().mrth_scene_new()
+    def __init__(self, handle=None):
+        self._h = handle if handle is not None else abi.host().mrth_scene_new()
         self.transforms = []  # every Transform handed to this scene (tests replay their ops)
+
+    @classmethod
+    def parse(cls, scene_id, width=1200, height=800, asset_dir=None):
+        """parseScene(sceneId) over the scene data files of asset_dir/scenes/."""
+        lib = abi.host()
+        h = lib.mrth_parse_scene(scene_id, width, height, asset_dir.encode() if asset_dir else None)
+        if not h:
+            raise MrtError(lib.mrth_last_error().decode())
+        return cls(h)
+
+    @classmethod
+    def load(cls, filename, width, height, asset_dir=None):
+        lib = abi.host()
+        h = lib.mrth_load_scene_file(filename.encode(), width, height, asset_dir.encode() if asset_dir else None)
+        if not h:
+            raise MrtError(lib.mrth_last_error().decode())
+        return cls(h)
 
     def _xf(self, xf):
         self.transforms.append(xf)
@@ -94,6 +111,11 @@ class Scene:
         rgb = np.ascontiguousarray(rgb, dtype=np.float32)
         h, w, _ = rgb.shape
         abi.host().mrth_material_set_image(self._h, mat, w, h, _fp(rgb.reshape(-1)), tex_xf._h if tex_xf else None)
+
+    def set_image_texture_file(self, mat, filename, tex_xf=None):
+        """m_texture = new image_texture(filename): a PNG or binary PPM file."""
+        if abi.host().mrth_material_set_image_file(self._h, mat, filename.encode(), tex_xf._h if tex_xf else None) != 0:
+            raise MrtError(abi.host().mrth_last_error().decode())
 
     def share_texture(self, from_mat, first, last):
         """Materials first..last use the texture of from_mat (the texels are stored once)."""

@@ -22,6 +22,13 @@ def asset(name):
     return os.path.join(ASSETS, name)
 
 
+def parse_scene(scene_id, width=1200, height=800):
+    """parseScene(sceneId) of the reference (example_scenes.cpp:1594-1647) for its Cook-Torrance scenes
+    9, 18, 19, 20 and 21, read from assets/scenes/scene<N>.scene; 1200x800 are the reference's WIDTH and
+    HEIGHT (example_scenes.h:4-5)."""
+    return Scene.parse(scene_id, width, height, ASSETS)
+
+
 def cornell(width=512, height=512):
     sc = Scene()
     frm, at = (-0.23, 2.585, 5.3), (-0.23, 2.585, -2.8)

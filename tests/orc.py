@@ -132,6 +132,7 @@ def ref():
         lib.ref_adapter_free.argtypes = [vp]
         lib.ref_scene_set_camera.argtypes = [vp, vp]
         lib.ref_material_set_checker.argtypes = [vp, C.c_int, vp, vp, vp]
+        lib.ref_material_set_image.argtypes = [vp, C.c_int, C.c_char_p, vp]
         lib.ref_load_png.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), vp, C.c_int64]
         lib.ref_save_image.argtypes = [C.c_char_p, C.c_int, C.c_int, vp]
         lib.ref_face_normals.argtypes = [C.c_int64, vp, C.c_int, vp, vp, vp]

@@ -3,9 +3,12 @@
 // exercising scene set-up, the loaders, the kd-tree build, flatten and the C-ABI's host-side
 // validation.  No GPU is touched: mrt_scene_create is expected to stop at "no device" or earlier.
 // usage: host_sanitize <assets directory>
-#include "mrt_host.hpp"
+#include "host_math.hpp" // the host library's internal header: mrt_host.hpp + the PNG decoder
 
 #include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <vector>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -104,6 +107,57 @@ int main( int argc, char** argv ) {
                 throw;
             }
             freeScene( s );
+        }
+        catch ( const std::runtime_error& ) {
+            threw = true;
+        }
+        CHECK( threw );
+    }
+    {
+        // PNG reader: the texture of scene 18, then the same bytes cut short and damaged (every
+        // outcome but a clean decode or a clean refusal is a sanitizer report)
+        const std::string png = assets + "/pf-s125-ake7011-a.png";
+        std::unique_ptr<texture> tex( image_texture( png.c_str() ) );
+        CHECK( tex && tex->width == 800 && tex->height == 533 && tex->texels.size() == 3u * 800 * 533 );
+        std::ifstream f( png, std::ios::binary );
+        std::vector<unsigned char> bytes( ( std::istreambuf_iterator<char>( f ) ), std::istreambuf_iterator<char>() );
+        uint32_t w = 0, h = 0;
+        std::vector<unsigned char> rgb;
+        CHECK( decode_png_rgb8( bytes.data(), bytes.size(), w, h, rgb ) && w == 800 && h == 533 );
+        for ( size_t cut : { (size_t)0, (size_t)7, (size_t)33, (size_t)57, (size_t)1000, bytes.size() / 2, bytes.size() - 13 } )
+            CHECK( !decode_png_rgb8( bytes.data(), cut, w, h, rgb ) );
+        uint32_t state = 12345u;
+        for ( int round = 0; round < 40; round++ ) {
+            std::vector<unsigned char> bad = bytes;
+            for ( int k = 0; k < 8; k++ ) {
+                state = state * 1664525u + 1013904223u;
+                bad[41 + ( state >> 8 ) % ( bad.size() - 41 )] ^= (unsigned char)( 1u << ( state & 7u ) );
+            }
+            decode_png_rgb8( bad.data(), bad.size(), w, h, rgb ); // either outcome
+        }
+    }
+    {
+        // parseScene over the scene data files, and a file with an error in it
+        for ( int id : { 9, 18, 19, 20, 21 } ) {
+            Scene* scene = parseScene( id, 120, 80, assets.c_str() );
+            CHECK( scene && scene->cam && !scene->objects.empty() );
+            KdTree* tree = initKdTree( scene, 2 );
+            std::unique_ptr<FlatScene> flat( flatten( scene, tree ) );
+            CHECK( flat->desc.n_objects == scene->objects.size() );
+            delete tree;
+            freeScene( scene );
+        }
+        bool threw = false;
+        try {
+            parseScene( 12, 120, 80, assets.c_str() );
+        }
+        catch ( const std::invalid_argument& ) {
+            threw = true;
+        }
+        CHECK( threw );
+        threw = false;
+        try {
+            loadSceneFile( ( assets + "/cornell-box.mtl" ).c_str(), 64, 64, assets.c_str() ); // not a scene file
         }
         catch ( const std::runtime_error& ) {
             threw = true;

@@ -528,3 +528,15 @@ def test_kind_buckets_do_not_change_the_frame():
     cpu, crs, _, _ = orc.oracle_render(flat.desc, render_params(160, 96, 3, 3, max_depth=8, seed=4), 0, threads=16)
     check_images(frames[0][0], cpu, 9)
     dev.close()
+
+
+@pytest.mark.parametrize("scene_id,w,h,sx,sy", [(9, 120, 80, 4, 4), (18, 150, 100, 4, 2), (19, 150, 100, 4, 2), (20, 120, 80, 2, 2)])
+def test_reference_example_scenes(scene_id, w, h, sx, sy):
+    """The reference's own Cook-Torrance example scenes, loaded by parseScene from their data files
+    (9: Cornell box + Suzanne + glass sphere lit by triangle lights; 18: what main.cpp renders, with
+    the PNG-textured, mirror, glass and rough spheres under the HDR map and a thin lens; 19: 98
+    spheres over the roughness x metalness grid; 20: bunny.obj), GPU against the oracle."""
+    gpu, cpu, rs, crs = render_both(scenes.parse_scene(scene_id, w, h), w, h, sx, sy, 5, 100 + scene_id)
+    check_images(gpu, cpu, sx * sy)
+    assert rs.paths == crs.paths == w * h * sx * sy
+    assert abs(int(rs.rays_closest) - int(crs.rays_closest)) <= 2e-3 * crs.rays_closest

@@ -364,3 +364,49 @@ def test_reference_side_adapter_flattens_like_the_product(built, name):
         for f in ("pos", "near_top_left", "dx_pixel", "dy_pixel", "x_dir", "up"):
             close(np.array(getattr(a.camera, f), np.float32), np.array(getattr(d.camera, f), np.float32), rel=2e-6, abs_=1e-7)
     lib.ref_adapter_free(h_)
+
+
+@pytest.mark.ref
+def test_reference_side_adapter_flattens_textures(built):
+    """The adapter on reference materials that carry a checker_texture and an image_texture of a PNG
+    file (what scene 18 attaches, example_scenes.cpp:1244; the reference keeps the pixels in a private
+    member): kind, size, colours, texture transform and every texel equal the product's tables for the
+    same scene."""
+    from raytracer_amd.host import Scene, Transform
+    lib = orc.ref()
+    png = scenes.asset("pf-s125-ake7011-a.png")
+    ops_img = [("scale", 0.5, 2.0, 1.0), ("rotate", 0, 0, 1, 30.0)]
+    ops_chk = [("scale", 0.25, 0.4, 1.0)]
+    sc = Scene()
+    sc.setSimpleCamera((0, 1, 6), (0, 0.5, 0), (0, 1, 0), 50, 64, 64, 0.0, 6.0)
+    mats = [sc.CreateMaterial(abi.MRT_MAT_SPECULAR, albedo=(0, 0, 0), roughness=0.1, metalness=0.01), sc.CreateMaterial(), sc.CreateMaterial()]
+    sc.set_image_texture_file(mats[0], png, cases.transform_from_ops(ops_img))
+    sc.set_checker(mats[2], (0.7, 0, 0), (0.3, 0, 0), cases.transform_from_ops(ops_chk))
+    xfs = [Transform().scale(0.5, 0.5, 0.5).translate((x, 0.5, 0)) for x in (-1.2, 0.0, 1.2)]
+    for m, t in zip(mats, xfs):
+        sc.add_sphere(t, m)
+    flat = sc.initKdTree().flatten(0)
+    d = flat.desc.contents
+    rs = orc.RefScene(flat.desc, orc.xf_ops_for(flat, sc))
+    # RefScene gives object i the material i
+    hx = orc.ref_transform_handle(ops_img)
+    lib.ref_material_set_image(rs.scene, 0, png.encode(), hx)
+    hc = orc.ref_transform_handle(ops_chk)
+    even, odd = np.array((0.7, 0, 0), np.float32), np.array((0.3, 0, 0), np.float32)
+    lib.ref_material_set_checker(rs.scene, 2, P(even), P(odd), hc)
+    h_ = lib.ref_adapter_flatten(rs.scene, rs.tree)
+    assert h_, "the adapter refused the scene"
+    a = lib.ref_adapter_desc(h_).contents
+    assert (a.n_textures, a.n_texels) == (d.n_textures, d.n_texels) == (2, 3 * 800 * 533)
+    assert [a.materials[i].texture for i in range(3)] == [d.materials[i].texture for i in range(3)] == [0, -1, 1]
+    for i in range(2):
+        ta, td = a.textures[i], d.textures[i]
+        assert (ta.kind, ta.width, ta.height, ta.texel_offset) == (td.kind, td.width, td.height, td.texel_offset)
+        for f in ("even", "odd"):
+            assert bits(np.array(getattr(ta, f))).tolist() == bits(np.array(getattr(td, f))).tolist()
+        for f in ("m", "inv", "t"):
+            assert bits(np.array(getattr(ta.xf, f))).tolist() == bits(np.array(getattr(td.xf, f))).tolist(), (i, f)
+    xa = np.ctypeslib.as_array(C.cast(a.texels, abi.u32p), shape=(a.n_texels,))
+    xd = np.ctypeslib.as_array(C.cast(d.texels, abi.u32p), shape=(d.n_texels,))
+    assert np.array_equal(xa, xd)
+    lib.ref_adapter_free(h_)
