@@ -12,7 +12,10 @@
 //
 // What is different from the reference: world-space boxes are computed once per object instead
 // of once per node, axis and object; the three per-axis event lists are generated in one pass;
-// sibling subtrees are built by OpenMP tasks.
+// sibling subtrees are built by OpenMP tasks, and in the large nodes near the root, where there are
+// fewer subtrees than threads, the three axes are sorted and swept by three tasks (each axis keeps
+// its own best candidate; they are merged in axis order with the same strict comparison, so the
+// outcome is that of the sequential loop).
 #include "host_math.hpp"
 
 #include <algorithm>
@@ -38,9 +41,9 @@ struct Event {
     int type;
 };
 enum { STARTING = 0, LYING = 1, ENDING = 2 };
-bool comp_events( Event i, Event j ) {
-    return i.b < j.b;
-}
+struct CompEvents { // the reference's comp_events (kdtree.cpp:311-313) as a functor the sort can inline
+    bool operator()( const Event& i, const Event& j ) const { return i.b < j.b; }
+};
 
 struct Prim {
     int kind;
@@ -73,7 +76,8 @@ float sah( const vec3& mn, const vec3& mx, float area, float p, int nl, int nr, 
 
 struct Builder {
     std::vector<Prim> prims;
-    int task_cutoff = 2048;
+    int task_cutoff = 2048;  // children with fewer objects together are built by the same thread
+    int axis_cutoff = 32768; // nodes from this size on sort and sweep their three axes in parallel
 
     void clipped( const Prim& p, const vec3& mn, const vec3& mx, vec3& minb, vec3& maxb ) const {
         minb = p.bmin;
@@ -85,59 +89,86 @@ struct Builder {
     }
 
     // kdtree.cpp:316-390
-    void findPlane( const KdTreeNode* node, std::vector<Event>* ev, float& p_, int& k_, float& c_ ) const {
-        c_ = INFINITY;
-        p_ = 0;
+    // events of the node's objects, per axis, in the reference's generation order
+    void generate( const KdTreeNode* node, std::vector<Event>* ev ) const {
+        const size_t n_obj = node->objects.size();
         for ( int k = 0; k < 3; k++ )
-            ev[k].clear();
+            ev[k].resize( 2 * n_obj );
+        Event *e0 = ev[0].data(), *e1 = ev[1].data(), *e2 = ev[2].data();
+        size_t m = 0;
         for ( int obj : node->objects ) {
             vec3 minb, maxb;
             clipped( prims[obj], node->min, node->max, minb, maxb );
             float dx = maxb.x - minb.x, dy = maxb.y - minb.y, dz = maxb.z - minb.z;
             bool planar = dx <= 0.001 || dy <= 0.001 || dz <= 0.001;
-            for ( int k = 0; k < 3; k++ ) {
-                if ( planar ) ev[k].push_back( Event { minb[k], LYING } );
-                else {
-                    ev[k].push_back( Event { minb[k], STARTING } );
-                    ev[k].push_back( Event { maxb[k], ENDING } );
-                }
+            if ( planar ) {
+                e0[m] = Event { minb.x, LYING }, e1[m] = Event { minb.y, LYING }, e2[m] = Event { minb.z, LYING };
+                m++;
+            }
+            else {
+                e0[m] = Event { minb.x, STARTING }, e1[m] = Event { minb.y, STARTING }, e2[m] = Event { minb.z, STARTING };
+                e0[m + 1] = Event { maxb.x, ENDING }, e1[m + 1] = Event { maxb.y, ENDING }, e2[m + 1] = Event { maxb.z, ENDING };
+                m += 2;
             }
         }
+        for ( int k = 0; k < 3; k++ )
+            ev[k].resize( m );
+    }
+    // sort + sweep of one axis: the first candidate of lowest cost on that axis
+    void sweep( const KdTreeNode* node, std::vector<Event>& events, int k, float area, float& p_, float& c_ ) const {
+        c_ = INFINITY;
+        p_ = 0;
+        std::sort( events.begin(), events.end(), CompEvents() );
+        const size_t n = events.size();
+        int nl = 0, np = 0, nr = (int)node->objects.size();
+        for ( size_t i = 0; i < n; i++ ) {
+            float p       = events[i].b;
+            int pStarting = 0, pEnding = 0, pLying = 0;
+            while ( i < n && events[i].b == p && events[i].type == ENDING ) {
+                pEnding++;
+                i++;
+            }
+            while ( i < n && events[i].b == p && events[i].type == LYING ) {
+                pLying++;
+                i++;
+            }
+            while ( i < n && events[i].b == p && events[i].type == STARTING ) {
+                pStarting++;
+                i++;
+            }
+            np = pLying;
+            nr -= pLying;
+            nr -= pEnding;
+            float c = sah( node->min, node->max, area, p, nl, nr, np, k );
+            if ( c < c_ && !( p <= node->min[k] ) && !( p >= node->max[k] ) ) {
+                c_ = c;
+                p_ = p;
+            }
+            nl += pStarting;
+            nl += pLying;
+            np = 0;
+        }
+    }
+    void findPlane( const KdTreeNode* node, std::vector<Event>* ev, bool axis_tasks, float& p_, int& k_, float& c_ ) const {
+        generate( node, ev );
         const float area = surfaceArea( node->min, node->max );
-        for ( int k = 0; k < 3; k++ ) {
-            std::vector<Event>& events = ev[k];
-            std::sort( events.begin(), events.end(), comp_events );
-            const size_t n = events.size();
-            int nl = 0, np = 0, nr = (int)node->objects.size();
-            for ( size_t i = 0; i < n; i++ ) {
-                float p       = events[i].b;
-                int pStarting = 0, pEnding = 0, pLying = 0;
-                while ( i < n && events[i].b == p && events[i].type == ENDING ) {
-                    pEnding++;
-                    i++;
-                }
-                while ( i < n && events[i].b == p && events[i].type == LYING ) {
-                    pLying++;
-                    i++;
-                }
-                while ( i < n && events[i].b == p && events[i].type == STARTING ) {
-                    pStarting++;
-                    i++;
-                }
-                np = pLying;
-                nr -= pLying;
-                nr -= pEnding;
-                float c = sah( node->min, node->max, area, p, nl, nr, np, k );
-                if ( c < c_ && !( p <= node->min[k] ) && !( p >= node->max[k] ) ) {
-                    c_ = c;
-                    p_ = p;
-                    k_ = k;
-                }
-                nl += pStarting;
-                nl += pLying;
-                np = 0;
-            }
+        float p[3], c[3];
+        if ( axis_tasks ) {
+#pragma omp task shared( ev, p, c ) firstprivate( node, area )
+            sweep( node, ev[1], 1, area, p[1], c[1] );
+#pragma omp task shared( ev, p, c ) firstprivate( node, area )
+            sweep( node, ev[2], 2, area, p[2], c[2] );
+            sweep( node, ev[0], 0, area, p[0], c[0] );
+#pragma omp taskwait
         }
+        else {
+            for ( int k = 0; k < 3; k++ )
+                sweep( node, ev[k], k, area, p[k], c[k] );
+        }
+        c_ = INFINITY;
+        p_ = 0;
+        for ( int k = 0; k < 3; k++ )
+            if ( c[k] < c_ ) c_ = c[k], p_ = p[k], k_ = k;
     }
 
     static bool boxOverlap( const vec3& mn, const vec3& mx, const vec3& aMin, const vec3& aMax ) {
@@ -155,10 +186,16 @@ struct Builder {
 
     // kdtree.cpp:392-464
     void subdivide( KdTreeNode* node ) const {
-        static thread_local std::vector<Event> ev[3];
+        static thread_local std::vector<Event> ev_small[3];
         float p = 0, c = 0;
         int axis = 0;
-        findPlane( node, ev, p, axis, c );
+        if ( (int)node->objects.size() >= axis_cutoff ) {
+            // its own event lists: while this thread waits for the two axis tasks it may run other
+            // tasks, which use the thread's shared lists
+            std::vector<Event> ev[3];
+            findPlane( node, ev, true, p, axis, c );
+        }
+        else findPlane( node, ev_small, false, p, axis, c );
         if ( c == INFINITY || c > 1.5 * node->objects.size() ) {
             node->leaf = true;
             return;
@@ -174,8 +211,13 @@ struct Builder {
         r->min[axis]    = p;
         node->left      = l;
         node->right     = r;
-        for ( int obj : node->objects ) {
-            const Prim& pr = prims[obj];
+        // two passes, so that the children's lists are allocated once at their final size
+        static thread_local std::vector<unsigned char> side;
+        const size_t n_obj = node->objects.size();
+        side.resize( n_obj );
+        size_t n_l = 0, n_r = 0;
+        for ( size_t i = 0; i < n_obj; i++ ) {
+            const Prim& pr = prims[node->objects[i]];
             bool inl, inr;
             if ( pr.kind == SPHERE ) {
                 inl = sphereOverlap( pr.center, pr.radius, l->min, l->max );
@@ -185,13 +227,27 @@ struct Builder {
                 inl = boxOverlap( pr.bmin, pr.bmax, l->min, l->max );
                 inr = boxOverlap( pr.bmin, pr.bmax, r->min, r->max );
             }
-            if ( inl ) l->objects.push_back( obj );
-            if ( inr ) r->objects.push_back( obj );
+            side[i] = (unsigned char)( ( inl ? 1 : 0 ) | ( inr ? 2 : 0 ) );
+            n_l += inl, n_r += inr;
+        }
+        l->objects.resize( n_l );
+        r->objects.resize( n_r );
+        {
+            int *pl = l->objects.data(), *pr = r->objects.data();
+            const int* src = node->objects.data();
+            for ( size_t i = 0; i < n_obj; i++ ) {
+                if ( side[i] & 1 ) *pl++ = src[i];
+                if ( side[i] & 2 ) *pr++ = src[i];
+            }
         }
         std::vector<int>().swap( node->objects );
 
-        const bool spawn = (int)l->objects.size() + (int)r->objects.size() >= task_cutoff;
-#pragma omp task if ( spawn ) firstprivate( l )
+        if ( (int)l->objects.size() + (int)r->objects.size() < task_cutoff ) {
+            subdivide( l );
+            subdivide( r );
+            return;
+        }
+#pragma omp task firstprivate( l )
         subdivide( l );
         subdivide( r );
 #pragma omp taskwait
