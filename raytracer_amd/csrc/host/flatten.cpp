@@ -1,10 +1,12 @@
 // Scene + KdTree -> the flat mrt_scene_desc handed to the C-ABI (see mrt.h, mrt_host.hpp).
 #include "host_math.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <deque>
 #include <map>
 #include <stdexcept>
+#include <unordered_map>
 
 namespace mrt {
 
@@ -41,33 +43,129 @@ struct TransformTable {
     }
 };
 
+// Writes the tree into the node and reference arrays.  A subtree occupies one contiguous range of
+// each (nodes in pre-order, children in adjacent slots; leaf lists in visiting order), so once the
+// sizes of the subtrees are known, disjoint subtrees are written by different threads into ranges
+// fixed beforehand: the arrays come out the same whatever the number of threads.
 struct Emitter {
     std::vector<mrt_kdnode>& nodes;
     std::vector<uint32_t>& refs;
     uint32_t depth = 0;
 
-    void leaf( const KdTreeNode* n, uint32_t at ) {
-        nodes[at].w0 = (uint32_t)refs.size();
-        nodes[at].w1 = 3u | ( (uint32_t)n->objects.size() << 2 );
-        for ( int o : n->objects )
-            refs.push_back( (uint32_t)o );
+    struct Size {
+        uint64_t nodes = 0, refs = 0; // nodes excluding the subtree's root (whose slot the parent reserves)
+    };
+    // sizes of the subtrees of at least `MEMO` nodes, filled by measure_all
+    static constexpr uint64_t MEMO = 512;
+    std::unordered_map<const KdTreeNode*, Size> memo;
+    Size measure_rec( const KdTreeNode* n, int spawn_levels, std::vector<std::pair<const KdTreeNode*, Size>>& found ) {
+        Size s;
+        if ( n->leaf ) {
+            s.refs = n->objects.size();
+            return s;
+        }
+        Size a, b;
+        if ( spawn_levels > 0 ) {
+            std::vector<std::pair<const KdTreeNode*, Size>> fa, fb;
+#pragma omp task shared( a, fa ) firstprivate( n, spawn_levels )
+            a = measure_rec( n->left, spawn_levels - 1, fa );
+            b = measure_rec( n->right, spawn_levels - 1, fb );
+#pragma omp taskwait
+            found.insert( found.end(), fa.begin(), fa.end() );
+            found.insert( found.end(), fb.begin(), fb.end() );
+        }
+        else {
+            a = measure_rec( n->left, 0, found );
+            b = measure_rec( n->right, 0, found );
+        }
+        s.nodes = 2 + a.nodes + b.nodes;
+        s.refs  = a.refs + b.refs;
+        if ( s.nodes >= MEMO ) found.emplace_back( n, s );
+        return s;
     }
-    uint32_t inner( const KdTreeNode* n, uint32_t at ) {
-        uint32_t l = (uint32_t)nodes.size();
-        nodes.resize( nodes.size() + 2 );
+    Size measure_all( const KdTreeNode* root ) {
+        std::vector<std::pair<const KdTreeNode*, Size>> found;
+        Size s;
+#pragma omp parallel
+#pragma omp single
+        s = measure_rec( root, 10, found );
+        memo.reserve( found.size() * 2 );
+        for ( const auto& f : found )
+            memo.emplace( f.first, f.second );
+        return s;
+    }
+    Size measure( const KdTreeNode* n ) const {
+        auto it = memo.find( n );
+        if ( it != memo.end() ) return it->second;
+        Size s; // fewer than MEMO nodes: counted on the spot
+        if ( n->leaf ) {
+            s.refs = n->objects.size();
+            return s;
+        }
+        Size a = measure( n->left ), b = measure( n->right );
+        s.nodes = 2 + a.nodes + b.nodes;
+        s.refs  = a.refs + b.refs;
+        return s;
+    }
+    // the subtree of n: its root goes to slot `at`, its other nodes from `node_at`, its references from `ref_at`
+    uint32_t write( const KdTreeNode* n, uint32_t at, uint64_t& node_at, uint64_t& ref_at, uint32_t d ) {
+        uint32_t deepest = d;
+        if ( n->leaf ) {
+            nodes[at].w0 = (uint32_t)ref_at;
+            nodes[at].w1 = 3u | ( (uint32_t)n->objects.size() << 2 );
+            for ( int o : n->objects )
+                refs[ref_at++] = (uint32_t)o;
+            return deepest;
+        }
+        const uint32_t l = (uint32_t)node_at;
+        node_at += 2;
         std::memcpy( &nodes[at].w0, &n->split, 4 );
         nodes[at].w1 = (uint32_t)n->axis | ( l << 2 );
-        return l;
+        deepest      = std::max( deepest, write( n->left, l, node_at, ref_at, d + 1 ) );
+        deepest      = std::max( deepest, write( n->right, l + 1, node_at, ref_at, d + 1 ) );
+        return deepest;
     }
-    void preorder( const KdTreeNode* n, uint32_t at, uint32_t d ) {
-        if ( d > depth ) depth = d;
-        if ( n->leaf ) {
-            leaf( n, at );
+    struct Job {
+        const KdTreeNode* n;
+        uint32_t at, d;
+        uint64_t node_at, ref_at;
+    };
+    // Splits the subtree of j into jobs of at most `grain` nodes (written later, in parallel); the
+    // inner nodes above them are written here.
+    void plan( const Job& j, uint64_t grain, std::vector<Job>& jobs ) {
+        if ( j.n->leaf ) {
+            jobs.push_back( j );
             return;
         }
-        uint32_t l = inner( n, at );
-        preorder( n->left, l, d + 1 );
-        preorder( n->right, l + 1, d + 1 );
+        Size a = measure( j.n->left ), b = measure( j.n->right );
+        if ( 2 + a.nodes + b.nodes <= grain ) {
+            jobs.push_back( j );
+            return;
+        }
+        if ( j.d > depth ) depth = j.d;
+        const uint32_t l = (uint32_t)j.node_at;
+        std::memcpy( &nodes[j.at].w0, &j.n->split, 4 );
+        nodes[j.at].w1 = (uint32_t)j.n->axis | ( l << 2 );
+        plan( Job { j.n->left, l, j.d + 1, j.node_at + 2, j.ref_at }, grain, jobs );
+        plan( Job { j.n->right, l + 1, j.d + 1, j.node_at + 2 + a.nodes, j.ref_at + a.refs }, grain, jobs );
+    }
+    void run( std::vector<Job>& jobs ) {
+        uint32_t deepest = depth;
+#pragma omp parallel for schedule( dynamic, 1 ) reduction( max : deepest )
+        for ( size_t i = 0; i < jobs.size(); i++ ) {
+            Job j      = jobs[i];
+            uint32_t v = write( j.n, j.at, j.node_at, j.ref_at, j.d );
+            if ( v > deepest ) deepest = v;
+        }
+        depth = deepest;
+    }
+    void preorder( const KdTreeNode* root ) {
+        Size s = measure_all( root );
+        nodes.resize( 1 + s.nodes );
+        refs.resize( s.refs );
+        std::vector<Job> jobs;
+        plan( Job { root, 0, 0, 1, 0 }, std::max<uint64_t>( 4096, s.nodes / 256 ), jobs );
+        run( jobs );
     }
     // Breadth-first for the first `top` nodes, so the levels every ray walks through are one
     // contiguous prefix of the array; everything below in pre-order, so a subtree is contiguous.
@@ -76,22 +174,39 @@ struct Emitter {
             const KdTreeNode* n;
             uint32_t at, d;
         };
+        Size total = measure_all( root );
+        nodes.resize( 1 + total.nodes );
+        refs.resize( total.refs );
+        uint64_t node_at = 1, ref_at = 0;
         std::deque<Item> q;
         q.push_back( Item { root, 0, 0 } );
-        while ( !q.empty() && nodes.size() < top ) {
+        while ( !q.empty() && node_at < top ) {
             Item it = q.front();
             q.pop_front();
             if ( it.d > depth ) depth = it.d;
             if ( it.n->leaf ) {
-                leaf( it.n, it.at );
+                nodes[it.at].w0 = (uint32_t)ref_at;
+                nodes[it.at].w1 = 3u | ( (uint32_t)it.n->objects.size() << 2 );
+                for ( int o : it.n->objects )
+                    refs[ref_at++] = (uint32_t)o;
                 continue;
             }
-            uint32_t l = inner( it.n, it.at );
+            const uint32_t l = (uint32_t)node_at;
+            node_at += 2;
+            std::memcpy( &nodes[it.at].w0, &it.n->split, 4 );
+            nodes[it.at].w1 = (uint32_t)it.n->axis | ( l << 2 );
             q.push_back( Item { it.n->left, l, it.d + 1 } );
             q.push_back( Item { it.n->right, l + 1, it.d + 1 } );
         }
-        for ( const Item& it : q )
-            preorder( it.n, it.at, it.d );
+        std::vector<Job> jobs;
+        const uint64_t grain = std::max<uint64_t>( 4096, total.nodes / 256 );
+        for ( const Item& it : q ) {
+            Size s = measure( it.n );
+            plan( Job { it.n, it.at, it.d, node_at, ref_at }, grain, jobs );
+            node_at += s.nodes;
+            ref_at += s.refs;
+        }
+        run( jobs );
     }
 };
 
@@ -209,8 +324,7 @@ FlatScene* flatten( Scene* scene, KdTree* tree, NodeLayout layout ) {
 
     Emitter em { fs->nodes, fs->refs };
     if ( tree->root ) {
-        fs->nodes.resize( 1 );
-        if ( layout == LAYOUT_PREORDER_PAIRS ) em.preorder( tree->root, 0, 0 );
+        if ( layout == LAYOUT_PREORDER_PAIRS ) em.preorder( tree->root );
         else em.bfs_top( tree->root, 1u << 13 );
     }
     fs->tree_depth = em.depth;

@@ -49,11 +49,12 @@ struct DevBuf {
         if ( count == 0 ) return hipSuccess;
         return hipMalloc( (void**)&p, count * sizeof( T ) );
     }
-    hipError_t upload( const std::vector<T>& v ) {
-        hipError_t e = alloc( v.size() );
-        if ( e != hipSuccess || v.empty() ) return e;
-        return hipMemcpy( p, v.data(), v.size() * sizeof( T ), hipMemcpyHostToDevice );
+    hipError_t upload( const T* v, size_t count ) {
+        hipError_t e = alloc( count );
+        if ( e != hipSuccess || count == 0 ) return e;
+        return hipMemcpy( p, v, count * sizeof( T ), hipMemcpyHostToDevice );
     }
+    hipError_t upload( const std::vector<T>& v ) { return upload( v.data(), v.size() ); }
     void release() {
         if ( p ) (void)hipFree( p );
         p = nullptr;
@@ -108,21 +109,21 @@ struct mrt_scene {
 namespace {
 
 // Walks the flattened tree on the host: every index must be in range, children must be stored
-// after their parent (which also rules out cycles), and the depth must fit the traversal stack.
-mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out ) {
+// after their parent (which also rules out cycles), no node may have two parents, and the depth must
+// fit the traversal stack.  level[n] receives the parity of node n's depth (2 = not part of the tree).
+mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out, std::vector<uint8_t>& level ) {
     *depth_out = 0;
+    level.clear();
     if ( d->n_nodes == 0 ) return MRT_OK;
     if ( !d->nodes ) return fail( MRT_ERR_INVALID, "nodes is NULL" );
     if ( d->n_refs && !d->refs ) return fail( MRT_ERR_INVALID, "refs is NULL" );
+    level.assign( d->n_nodes, 2 );
+    level[0] = 0;
     std::vector<std::pair<uint32_t, uint32_t>> stack;
     stack.emplace_back( 0u, 0u );
-    uint64_t visited = 0;
     while ( !stack.empty() ) {
         auto [node, depth] = stack.back();
         stack.pop_back();
-        // a tree visits every node once: more visits than nodes means a node with two parents
-        // (checked here, so that a malformed description cannot make this walk exponential)
-        if ( ++visited > d->n_nodes ) return fail( MRT_ERR_INVALID, "tree visits more nodes than it has" );
         if ( depth > *depth_out ) *depth_out = depth;
         const mrt_kdnode& n = d->nodes[node];
         if ( ( n.w1 & 3u ) == 3u ) {
@@ -137,6 +138,9 @@ mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out ) {
         }
         uint32_t left = n.w1 >> 2;
         if ( left <= node || (uint64_t)left + 1 >= d->n_nodes ) return fail( MRT_ERR_INVALID, "child index out of range or not after its parent" );
+        // every node is entered once (so a malformed description cannot make this walk exponential)
+        if ( level[left] != 2 || level[left + 1] != 2 ) return fail( MRT_ERR_INVALID, "a tree node has two parents" );
+        level[left] = level[left + 1] = (uint8_t)( ( depth + 1 ) & 1u );
         stack.emplace_back( left, depth + 1 );
         stack.emplace_back( left + 1, depth + 1 );
     }
@@ -146,24 +150,10 @@ mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out ) {
 
 // The tree as the kernels read it: one 32-byte record (two uint4) per node of even depth, holding
 // the node and its two children (layout in device_trace.hpp); records follow the order of the
-// caller's nodes.  Expects a tree that passed validate_tree.
-mrt_status build_tree_records( const mrt_scene_desc* d, std::vector<uint4>& nodes ) {
+// caller's nodes.  Expects the depth parities validate_tree made of a tree that passed it.
+mrt_status build_tree_records( const mrt_scene_desc* d, const std::vector<uint8_t>& level, std::vector<uint4>& nodes ) {
     nodes.clear();
     if ( d->n_nodes ) {
-        std::vector<uint8_t> level( d->n_nodes, 2 ); // depth parity, 2 = not reached
-        std::vector<uint32_t> todo( 1, 0u );
-        level[0] = 0;
-        while ( !todo.empty() ) {
-            const uint32_t n = todo.back();
-            todo.pop_back();
-            const uint32_t w1 = d->nodes[n].w1;
-            if ( ( w1 & 3u ) == 3u ) continue;
-            for ( uint32_t c = w1 >> 2; c <= ( w1 >> 2 ) + 1; c++ ) {
-                if ( level[c] != 2 ) return fail( MRT_ERR_INVALID, "a tree node has two parents" );
-                level[c] = level[n] ^ 1;
-                todo.push_back( c );
-            }
-        }
         std::vector<uint32_t> record( d->n_nodes, 0 );
         uint32_t n_records = 0;
         for ( uint32_t i = 0; i < d->n_nodes; i++ )
@@ -179,21 +169,32 @@ mrt_status build_tree_records( const mrt_scene_desc* d, std::vector<uint4>& node
         };
         // the kernels form a record's byte offset (record << 5) in 32 bits
         if ( n_records >= ( 1u << 27 ) ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree too large (limit: 2^27 nodes of even depth)" );
-        nodes.assign( 2 * (size_t)n_records, make_uint4( 0, 0, 0, 0 ) );
-        for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
-            if ( level[i] != 0 ) continue;
-            const uint32_t w0 = d->nodes[i].w0, w1 = d->nodes[i].w1;
-            uint32_t l[3] = { 0, 0, 0 }, r[3] = { 0, 0, 0 };
-            uint32_t h0 = 0, h1 = 3;
-            if ( ( w1 & 3u ) == 3u ) child( i, l ); // a leaf of even depth: no head step
-            else {
-                h0 = w0, h1 = w1 & 3u;
-                child( w1 >> 2, l );
-                child( ( w1 >> 2 ) + 1, r );
+        nodes.resize( 2 * (size_t)n_records );
+        auto fill = [&]( uint32_t begin, uint32_t end ) {
+            for ( uint32_t i = begin; i < end; i++ ) {
+                if ( level[i] != 0 ) continue;
+                const uint32_t w0 = d->nodes[i].w0, w1 = d->nodes[i].w1;
+                uint32_t l[3] = { 0, 0, 0 }, r[3] = { 0, 0, 0 };
+                uint32_t h0 = 0, h1 = 3;
+                if ( ( w1 & 3u ) == 3u ) child( i, l ); // a leaf of even depth: no head step
+                else {
+                    h0 = w0, h1 = w1 & 3u;
+                    child( w1 >> 2, l );
+                    child( ( w1 >> 2 ) + 1, r );
+                }
+                nodes[2 * (size_t)record[i]]     = make_uint4( h0, h1, l[0], l[1] );
+                nodes[2 * (size_t)record[i] + 1] = make_uint4( r[0], r[1], l[2], r[2] );
             }
-            nodes[2 * (size_t)record[i]]     = make_uint4( h0, h1, l[0], l[1] );
-            nodes[2 * (size_t)record[i] + 1] = make_uint4( r[0], r[1], l[2], r[2] );
-        }
+        };
+        // every record is written by the one thread whose range holds its node
+        const uint32_t n_threads = d->n_nodes < ( 1u << 18 ) ? 1u : std::min( 8u, std::max( 1u, std::thread::hardware_concurrency() ) );
+        const uint32_t per       = ( d->n_nodes + n_threads - 1 ) / n_threads;
+        std::vector<std::thread> workers;
+        for ( uint32_t t = 1; t < n_threads; t++ )
+            workers.emplace_back( fill, std::min( d->n_nodes, t * per ), std::min( d->n_nodes, ( t + 1 ) * per ) );
+        fill( 0, std::min( d->n_nodes, per ) );
+        for ( std::thread& w : workers )
+            w.join();
     }
     return MRT_OK;
 }
@@ -297,10 +298,14 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     if ( d->n_texels && !d->texels ) return fail( MRT_ERR_INVALID, "texels is NULL" );
     if ( d->n_lights && !d->lights ) return fail( MRT_ERR_INVALID, "lights is NULL" );
     uint32_t depth = 0;
-    mrt_status vs  = validate_tree( d, &depth );
-    if ( vs != MRT_OK ) return vs;
     std::vector<uint4> nodes;
-    vs = build_tree_records( d, nodes );
+    mrt_status vs;
+    {
+        std::vector<uint8_t> level;
+        vs = validate_tree( d, &depth, level );
+        if ( vs != MRT_OK ) return vs;
+        vs = build_tree_records( d, level, nodes );
+    }
     if ( vs != MRT_OK ) return vs;
     for ( uint32_t i = 0; i < d->n_out_of_tree; i++ ) {
         if ( d->out_of_tree[i] >= d->n_objects ) return fail( MRT_ERR_INVALID, "out_of_tree index out of range" );
@@ -367,10 +372,10 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     s->no_emitters = no_emitters;
     s->mixed_kinds = ( kinds_seen & ( kinds_seen - 1u ) ) != 0u;
     HIP_TRY( s->nodes.upload( nodes ) );
-    HIP_TRY( s->refs.upload( std::vector<uint32_t>( d->refs, d->refs + d->n_refs ) ) );
+    HIP_TRY( s->refs.upload( d->refs, d->n_refs ) );
     HIP_TRY( s->prims.upload( prims ) );
     HIP_TRY( s->xforms.upload( xforms ) );
-    HIP_TRY( s->out_of_tree.upload( std::vector<uint32_t>( d->out_of_tree, d->out_of_tree + d->n_out_of_tree ) ) );
+    HIP_TRY( s->out_of_tree.upload( d->out_of_tree, d->n_out_of_tree ) );
     HIP_TRY( hipMalloc( (void**)&s->d_stats, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ) ) );
     HIP_TRY( hipEventCreateWithFlags( &s->order, hipEventDisableTiming ) );
     HIP_TRY( hipEventRecord( s->order, 0 ) );
