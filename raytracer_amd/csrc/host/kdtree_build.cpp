@@ -12,15 +12,23 @@
 //
 // What is different from the reference: world-space boxes are computed once per object instead
 // of once per node, axis and object; the three per-axis event lists are generated in one pass;
-// sibling subtrees are built by OpenMP tasks, and in the large nodes near the root, where there are
-// fewer subtrees than threads, the three axes are sorted and swept by three tasks (each axis keeps
-// its own best candidate; they are merged in axis order with the same strict comparison, so the
-// outcome is that of the sequential loop).
+// subtrees are built by a pool of threads that always takes the largest node waiting (the SAH cuts
+// off small pieces for many levels, so the order in which nodes are taken decides how long the
+// threads stay busy), and in the large nodes near the root, where there are fewer nodes than
+// threads, the three axes are sorted and swept as three jobs (each axis keeps its own best
+// candidate; they are merged in axis order with the same strict comparison, so the outcome is that
+// of the sequential loop).
 #include "host_math.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
 #include <omp.h>
+#include <queue>
+#include <thread>
 
 namespace mrt {
 
@@ -76,8 +84,8 @@ float sah( const vec3& mn, const vec3& mx, float area, float p, int nl, int nr, 
 
 struct Builder {
     std::vector<Prim> prims;
-    int task_cutoff = 2048;  // children with fewer objects together are built by the same thread
-    int axis_cutoff = 32768; // nodes from this size on sort and sweep their three axes in parallel
+    size_t node_cutoff = 4096;  // a node with fewer objects is built, subtree and all, by the thread that made it
+    size_t axis_cutoff = 32768; // nodes from this size on sort and sweep their three axes as three jobs
 
     void clipped( const Prim& p, const vec3& mn, const vec3& mx, vec3& minb, vec3& maxb ) const {
         minb = p.bmin;
@@ -149,27 +157,6 @@ struct Builder {
             np = 0;
         }
     }
-    void findPlane( const KdTreeNode* node, std::vector<Event>* ev, bool axis_tasks, float& p_, int& k_, float& c_ ) const {
-        generate( node, ev );
-        const float area = surfaceArea( node->min, node->max );
-        float p[3], c[3];
-        if ( axis_tasks ) {
-#pragma omp task shared( ev, p, c ) firstprivate( node, area )
-            sweep( node, ev[1], 1, area, p[1], c[1] );
-#pragma omp task shared( ev, p, c ) firstprivate( node, area )
-            sweep( node, ev[2], 2, area, p[2], c[2] );
-            sweep( node, ev[0], 0, area, p[0], c[0] );
-#pragma omp taskwait
-        }
-        else {
-            for ( int k = 0; k < 3; k++ )
-                sweep( node, ev[k], k, area, p[k], c[k] );
-        }
-        c_ = INFINITY;
-        p_ = 0;
-        for ( int k = 0; k < 3; k++ )
-            if ( c[k] < c_ ) c_ = c[k], p_ = p[k], k_ = k;
-    }
 
     static bool boxOverlap( const vec3& mn, const vec3& mx, const vec3& aMin, const vec3& aMax ) {
         return !( ( mn.x > aMax.x ) || ( mx.x < aMin.x ) || ( mn.y > aMax.y ) || ( mx.y < aMin.y ) || ( mn.z > aMax.z ) || ( mx.z < aMin.z ) );
@@ -184,21 +171,87 @@ struct Builder {
         return dot( seg, seg ) < ( r * r );
     }
 
-    // kdtree.cpp:392-464
-    void subdivide( KdTreeNode* node ) const {
+    // ---------------------------------------------------------------- the pool
+    // Two kinds of work: nodes to split (largest first) and single axes of a large node (before any
+    // node: another thread is waiting for them).  `open` counts the nodes queued or being split;
+    // the build is over when it reaches zero.
+    struct AxisJob {
+        const KdTreeNode* node;
+        std::vector<Event>* events;
+        int k;
+        float area;
+        float *p, *c;
+        std::atomic<int>* left;
+    };
+    struct BySize {
+        bool operator()( const KdTreeNode* a, const KdTreeNode* b ) const { return a->objects.size() < b->objects.size(); }
+    };
+    std::mutex m;
+    std::condition_variable wake;
+    std::priority_queue<KdTreeNode*, std::vector<KdTreeNode*>, BySize> nodes_waiting;
+    std::vector<AxisJob> axes_waiting;
+    size_t open = 0;
+    bool parallel = false;
+    std::exception_ptr failure;
+
+    void run_axis( const AxisJob& j ) const {
+        sweep( j.node, *j.events, j.k, j.area, *j.p, *j.c );
+        j.left->fetch_sub( 1, std::memory_order_release );
+    }
+
+    void findPlane( const KdTreeNode* node, float& p_, int& k_, float& c_ ) {
         static thread_local std::vector<Event> ev_small[3];
+        const float area = surfaceArea( node->min, node->max );
+        float p[3], c[3];
+        if ( parallel && node->objects.size() >= axis_cutoff ) {
+            // its own event lists: while this thread waits for the other two axes it runs axis jobs
+            // of other nodes, and they must not share its lists
+            std::vector<Event> ev[3];
+            generate( node, ev );
+            std::atomic<int> left( 2 );
+            {
+                std::lock_guard<std::mutex> g( m );
+                axes_waiting.push_back( AxisJob { node, &ev[1], 1, area, &p[1], &c[1], &left } );
+                axes_waiting.push_back( AxisJob { node, &ev[2], 2, area, &p[2], &c[2], &left } );
+            }
+            wake.notify_all();
+            sweep( node, ev[0], 0, area, p[0], c[0] );
+            // Help until both are done.  Its own two jobs are in the list until somebody takes
+            // them, so a thread that finds the list empty only waits for jobs already running.
+            while ( left.load( std::memory_order_acquire ) != 0 ) {
+                AxisJob j {};
+                bool got = false;
+                {
+                    std::lock_guard<std::mutex> g( m );
+                    if ( !axes_waiting.empty() ) {
+                        j = axes_waiting.back();
+                        axes_waiting.pop_back();
+                        got = true;
+                    }
+                }
+                if ( got ) run_axis( j );
+                else std::this_thread::yield();
+            }
+        }
+        else {
+            generate( node, ev_small );
+            for ( int k = 0; k < 3; k++ )
+                sweep( node, ev_small[k], k, area, p[k], c[k] );
+        }
+        c_ = INFINITY;
+        p_ = 0;
+        for ( int k = 0; k < 3; k++ )
+            if ( c[k] < c_ ) c_ = c[k], p_ = p[k], k_ = k;
+    }
+
+    // kdtree.cpp:392-464: one node; false when it became a leaf
+    bool split( KdTreeNode* node ) {
         float p = 0, c = 0;
         int axis = 0;
-        if ( (int)node->objects.size() >= axis_cutoff ) {
-            // its own event lists: while this thread waits for the two axis tasks it may run other
-            // tasks, which use the thread's shared lists
-            std::vector<Event> ev[3];
-            findPlane( node, ev, true, p, axis, c );
-        }
-        else findPlane( node, ev_small, false, p, axis, c );
+        findPlane( node, p, axis, c );
         if ( c == INFINITY || c > 1.5 * node->objects.size() ) {
             node->leaf = true;
-            return;
+            return false;
         }
         KdTreeNode* l = new KdTreeNode();
         KdTreeNode* r = new KdTreeNode();
@@ -241,16 +294,72 @@ struct Builder {
             }
         }
         std::vector<int>().swap( node->objects );
+        return true;
+    }
+    void subtree( KdTreeNode* node ) { // by this thread alone
+        if ( !split( node ) ) return;
+        subtree( node->left );
+        subtree( node->right );
+    }
 
-        if ( (int)l->objects.size() + (int)r->objects.size() < task_cutoff ) {
-            subdivide( l );
-            subdivide( r );
+    void worker() {
+        std::unique_lock<std::mutex> lock( m );
+        for ( ;; ) {
+            if ( failure ) return;
+            if ( !axes_waiting.empty() ) {
+                AxisJob j = axes_waiting.back();
+                axes_waiting.pop_back();
+                lock.unlock();
+                run_axis( j ); // sorts and compares: nothing in it throws
+                lock.lock();
+                continue;
+            }
+            if ( !nodes_waiting.empty() ) {
+                KdTreeNode* node = nodes_waiting.top();
+                nodes_waiting.pop();
+                lock.unlock();
+                KdTreeNode* kids[2] = { nullptr, nullptr };
+                try {
+                    if ( node->objects.size() < node_cutoff ) subtree( node );
+                    else if ( split( node ) ) kids[0] = node->left, kids[1] = node->right;
+                }
+                catch ( ... ) {
+                    lock.lock();
+                    if ( !failure ) failure = std::current_exception();
+                    wake.notify_all();
+                    return;
+                }
+                lock.lock();
+                for ( KdTreeNode* k : kids )
+                    if ( k ) {
+                        nodes_waiting.push( k );
+                        open++;
+                    }
+                open--;
+                if ( open == 0 || kids[0] ) wake.notify_all();
+                continue;
+            }
+            if ( open == 0 ) return;
+            wake.wait( lock );
+        }
+    }
+
+    void build( KdTreeNode* root, int n_threads ) {
+        if ( n_threads <= 1 ) {
+            parallel = false;
+            subtree( root );
             return;
         }
-#pragma omp task firstprivate( l )
-        subdivide( l );
-        subdivide( r );
-#pragma omp taskwait
+        parallel = true;
+        nodes_waiting.push( root );
+        open = 1;
+        std::vector<std::thread> pool;
+        for ( int t = 1; t < n_threads; t++ )
+            pool.emplace_back( [this] { worker(); } );
+        worker();
+        for ( std::thread& t : pool )
+            t.join();
+        if ( failure ) std::rethrow_exception( failure );
     }
 };
 
@@ -319,10 +428,8 @@ KdTree* initKdTree( Scene* scene, int n_threads ) {
     root->objects.assign( tree->inTree.begin(), tree->inTree.end() );
     tree->root = root;
 
-    if ( n_threads < 1 ) n_threads = omp_get_max_threads();
-#pragma omp parallel num_threads( n_threads )
-#pragma omp single
-    b.subdivide( root );
+    if ( n_threads < 1 ) n_threads = omp_get_max_threads(); // honours OMP_NUM_THREADS, like the rest of the host library
+    b.build( root, n_threads );
     return tree;
 }
 
