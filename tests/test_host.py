@@ -580,3 +580,27 @@ def test_png_reader_against_the_references_lodepng(built, tmp_path):
         assert lib.ref_load_png(path.encode(), C.byref(ww), C.byref(hh), orc._p(px), px.size) == 0, path
         assert (hh.value, ww.value) == got.shape[:2]
         assert np.array_equal(got, px), path
+
+
+def _flat_digest_script():
+    return ("import hashlib, sys; sys.path.insert(0, %r)\n"
+            "from raytracer_amd import scenes\n"
+            "sc = scenes.bunny_ibl(64, 64, env=None)  # 69 451 triangles: node jobs, axis jobs and serial subtrees\n"
+            "tree = sc.initKdTree(int(sys.argv[1]))\n"
+            "for layout in (0, 1):\n"
+            "    n, r = tree.flatten(layout).nodes()\n"
+            "    print(hashlib.sha256(n.tobytes() + r.tobytes()).hexdigest())\n") % ROOT
+
+
+def test_tree_and_flatten_do_not_depend_on_the_thread_count(built):
+    """The builder's thread pool and flatten's parallel subtree writes give the same bytes whatever the
+    number of threads (1, 3 and 8 builder threads; OMP_NUM_THREADS 1 and 8 for flatten)."""
+    import subprocess
+    import sys
+    out = set()
+    for threads, omp in ((1, "1"), (3, "8"), (8, "2")):
+        env = dict(os.environ, OMP_NUM_THREADS=omp)
+        r = subprocess.run([sys.executable, "-c", _flat_digest_script(), str(threads)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.add(tuple(l for l in r.stdout.split() if len(l) == 64))
+    assert len(out) == 1 and len(next(iter(out))) == 2, out
