@@ -233,7 +233,11 @@ typedef struct mrt_render_stats {
 } mrt_render_stats;
 
 /* initKdTree + the Scene the reference hands to its integrator (kdtree.h:35, scene.h:19-43),
- * uploaded to `device` in the library's own layout. */
+ * uploaded to `device` in the library's own layout.  That layout keeps the objects in the order in
+ * which the tree's leaves first reference them (so a mesh stored in any order traverses alike); the
+ * order inside a leaf's list, which decides ties, is the caller's, and every object index that
+ * leaves the library (mrt_hits.prim) is the caller's.  MRT_OBJECT_ORDER=input in the environment
+ * keeps the caller's order (measurements only). */
 mrt_status mrt_scene_create( const mrt_scene_desc* desc, int device, mrt_scene** out );
 void mrt_scene_destroy( mrt_scene* scene );
 

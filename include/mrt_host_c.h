@@ -40,6 +40,8 @@ int mrth_material_set_checker( void* scene, int id, const float* even3, const fl
 int mrth_material_set_image( void* scene, int id, uint32_t w, uint32_t h, const float* rgb, void* tex_xf );
 /* materials first_id..last_id use the texture object of material from_id (one copy of the texels) */
 int mrth_materials_share_texture( void* scene, int from_id, int first_id, int last_id );
+/* scene->objects into a pseudo-random order (measurements: a mesh without locality in its file order) */
+void mrth_shuffle_objects( void* scene, uint64_t seed );
 int mrth_n_objects( void* scene );
 int mrth_n_materials( void* scene );
 int mrth_n_lights( void* scene );

@@ -168,6 +168,7 @@ def host():
             "mrth_material_set_checker": (ci, [vp, ci, f32p, f32p, vp]),
             "mrth_material_set_image": (ci, [vp, ci, C.c_uint32, C.c_uint32, f32p, vp]),
             "mrth_materials_share_texture": (ci, [vp, ci, ci, ci]),
+            "mrth_shuffle_objects": (None, [vp, C.c_uint64]),
             "mrth_n_objects": (ci, [vp]),
             "mrth_n_materials": (ci, [vp]),
             "mrth_n_lights": (ci, [vp]),

@@ -199,6 +199,17 @@ int mrth_materials_share_texture( void* scene_, int from_id, int first_id, int l
         scene->GetMaterial( id ).m_texture = t;
     return 0;
 }
+// Puts scene->objects into a pseudo-random order (Fisher-Yates on a 64-bit LCG): a mesh whose file
+// order carries no locality, for measurements.
+void mrth_shuffle_objects( void* scene_, uint64_t seed ) {
+    auto& objs     = static_cast<Scene*>( scene_ )->objects;
+    uint64_t state = seed * 6364136223846793005ull + 1442695040888963407ull;
+    for ( size_t i = objs.size(); i > 1; i-- ) {
+        state    = state * 6364136223846793005ull + 1442695040888963407ull;
+        size_t j = (size_t)( ( state >> 33 ) % i );
+        std::swap( objs[i - 1], objs[j] );
+    }
+}
 int mrth_n_objects( void* scene ) {
     return (int)static_cast<Scene*>( scene )->objects.size();
 }

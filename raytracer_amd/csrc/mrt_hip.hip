@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <memory>
 #include <mutex>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -75,6 +76,7 @@ struct mrt_scene {
     DevBuf<float4> prims;
     DevBuf<DXf> xforms;
     DevBuf<uint32_t> out_of_tree;
+    DevBuf<uint32_t> object_of; // the caller's index of the object the library keeps at a given place (see mrt_scene_create)
     // shading tables
     DevBuf<float> shade_n;  // [n][9]
     DevBuf<float> shade_uv; // [n][6]
@@ -298,20 +300,76 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     if ( d->n_texels && !d->texels ) return fail( MRT_ERR_INVALID, "texels is NULL" );
     if ( d->n_lights && !d->lights ) return fail( MRT_ERR_INVALID, "lights is NULL" );
     uint32_t depth = 0;
-    std::vector<uint4> nodes;
-    mrt_status vs;
-    {
-        std::vector<uint8_t> level;
-        vs = validate_tree( d, &depth, level );
-        if ( vs != MRT_OK ) return vs;
-        vs = build_tree_records( d, level, nodes );
-    }
+    std::vector<uint8_t> level;
+    mrt_status vs = validate_tree( d, &depth, level );
     if ( vs != MRT_OK ) return vs;
     for ( uint32_t i = 0; i < d->n_out_of_tree; i++ ) {
         if ( d->out_of_tree[i] >= d->n_objects ) return fail( MRT_ERR_INVALID, "out_of_tree index out of range" );
         // kdtree.cpp:64: planes, and only planes, stay outside the tree
         if ( d->obj_kind[d->out_of_tree[i]] != MRT_PLANE ) return fail( MRT_ERR_INVALID, "out_of_tree may list planes only" );
     }
+    for ( uint32_t i = 0; i < d->n_objects; i++ ) {
+        if ( d->obj_material[i] >= d->n_materials ) return fail( MRT_ERR_INVALID, "object material out of range" );
+        if ( d->obj_transform[i] >= d->n_transforms ) return fail( MRT_ERR_INVALID, "object transform out of range" );
+    }
+
+    // The library keeps the objects in the order in which the leaves first reference them (leaves in
+    // node order, i.e. depth-first below the top of the tree), so that the primitive records a ray
+    // pulls in one region of the tree lie together in memory whatever order the caller's mesh came
+    // in; objects no leaf references (the planes) follow.  Every per-object table and every object
+    // index of the description is rewritten accordingly; the order inside a leaf's list, which decides
+    // ties, is untouched, and mrt_intersect translates hit indices back (object_of).
+    // MRT_OBJECT_ORDER=input in the environment keeps the caller's order (for measurements).
+    const uint32_t n_obj = d->n_objects;
+    std::vector<uint32_t> place( n_obj ), object_of( n_obj );
+    {
+        const char* keep = std::getenv( "MRT_OBJECT_ORDER" );
+        uint32_t next    = 0;
+        if ( keep && std::strcmp( keep, "input" ) == 0 ) {
+            for ( uint32_t o = 0; o < n_obj; o++ )
+                place[o] = o;
+        }
+        else {
+            std::fill( place.begin(), place.end(), 0xffffffffu );
+            for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
+                const uint32_t w1 = d->nodes[i].w1;
+                if ( level[i] == 2 || ( w1 & 3u ) != 3u ) continue; // not part of the tree / not a leaf
+                for ( uint32_t k = 0; k < ( w1 >> 2 ); k++ ) {
+                    const uint32_t o = d->refs[d->nodes[i].w0 + k];
+                    if ( place[o] == 0xffffffffu ) place[o] = next++;
+                }
+            }
+            for ( uint32_t o = 0; o < n_obj; o++ )
+                if ( place[o] == 0xffffffffu ) place[o] = next++;
+        }
+        for ( uint32_t o = 0; o < n_obj; o++ )
+            object_of[place[o]] = o;
+    }
+    std::vector<uint8_t> r_kind( n_obj );
+    std::vector<uint32_t> r_material( n_obj ), r_transform( n_obj ), r_refs( d->n_refs ), r_out( d->n_out_of_tree );
+    std::vector<float> r_p( 9 * (size_t)n_obj ), r_n( 9 * (size_t)n_obj ), r_uv( 6 * (size_t)n_obj ), r_sphere( 4 * (size_t)n_obj );
+    for ( uint32_t o = 0; o < n_obj; o++ ) {
+        const size_t t = place[o];
+        r_kind[t] = d->obj_kind[o], r_material[t] = d->obj_material[o], r_transform[t] = d->obj_transform[o];
+        std::memcpy( &r_p[9 * t], d->tri_p + 9 * (size_t)o, 36 );
+        std::memcpy( &r_n[9 * t], d->tri_n + 9 * (size_t)o, 36 );
+        std::memcpy( &r_uv[6 * t], d->tri_uv + 6 * (size_t)o, 24 );
+        std::memcpy( &r_sphere[4 * t], d->sphere + 4 * (size_t)o, 16 );
+    }
+    for ( uint32_t i = 0; i < d->n_refs; i++ )
+        r_refs[i] = d->refs[i] < n_obj ? place[d->refs[i]] : 0u; // references outside every leaf's list are not validated (nor read)
+    for ( uint32_t i = 0; i < d->n_out_of_tree; i++ )
+        r_out[i] = place[d->out_of_tree[i]];
+    mrt_scene_desc reordered = *d;
+    reordered.obj_kind = r_kind.data(), reordered.obj_material = r_material.data(), reordered.obj_transform = r_transform.data();
+    reordered.tri_p = r_p.data(), reordered.tri_n = r_n.data(), reordered.tri_uv = r_uv.data(), reordered.sphere = r_sphere.data();
+    reordered.refs = r_refs.data(), reordered.out_of_tree = r_out.data();
+    d = &reordered;
+
+    std::vector<uint4> nodes;
+    vs = build_tree_records( d, level, nodes );
+    if ( vs != MRT_OK ) return vs;
+    level = std::vector<uint8_t>();
 
     int n_dev = 0;
     HIP_TRY( hipGetDeviceCount( &n_dev ) );
@@ -376,6 +434,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     HIP_TRY( s->prims.upload( prims ) );
     HIP_TRY( s->xforms.upload( xforms ) );
     HIP_TRY( s->out_of_tree.upload( d->out_of_tree, d->n_out_of_tree ) );
+    HIP_TRY( s->object_of.upload( object_of ) );
     HIP_TRY( hipMalloc( (void**)&s->d_stats, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ) ) );
     HIP_TRY( hipEventCreateWithFlags( &s->order, hipEventDisableTiming ) );
     HIP_TRY( hipEventRecord( s->order, 0 ) );
@@ -440,6 +499,7 @@ struct BatchIO {
     const float *ox, *oy, *oz, *dx, *dy, *dz, *tmin, *tmax;
     int32_t* prim;
     float *t, *u, *v;
+    const uint32_t* object_of; // the library's object order -> the caller's indices
     MRT_DEV void load( uint32_t i, uint32_t& tag, V3& o, V3& d, float& t0, float& t1 ) const {
         tag = i;
         o   = mk3( ox[i], oy[i], oz[i] );
@@ -448,7 +508,7 @@ struct BatchIO {
         t1  = tmax[i];
     }
     MRT_DEV void store( uint32_t i, bool, const DHit& h ) const {
-        prim[i] = h.prim;
+        prim[i] = h.prim >= 0 ? (int32_t)object_of[h.prim] : h.prim;
         t[i]    = h.t;
         u[i]    = h.u;
         v[i]    = h.v;
@@ -517,7 +577,7 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
     HIP_TRY( hipMemsetAsync( sc->d_stats, 0, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ), stream ) );
     const dim3 block( MRT_TRACE_BLOCK );
     unsigned long long* ds = (unsigned long long*)sc->d_stats;
-    const BatchIO io { din[0], din[1], din[2], din[3], din[4], din[5], din[6], din[7], dprim, dt, du, dv };
+    const BatchIO io { din[0], din[1], din[2], din[3], din[4], din[5], din[6], din[7], dprim, dt, du, dv, sc->object_of.p };
 #define LAUNCH( A, S ) \
     hipLaunchKernelGGL( ( trace_batch_kernel<A, S> ), dim3( trace_grid_blocks( trace_batch_kernel<A, S>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, (uint32_t*)( sc->d_stats + 8 ), ds )
     if ( flags == MRT_ANY_HIT ) {
@@ -600,7 +660,7 @@ extern "C" mrt_status mrt_intersect_noalloc( mrt_scene* sc, uint64_t n, const mr
     hipStream_t stream = (hipStream_t)stream_;
     // the deal counters must start at zero; the array keeps the last call's contents
     HIP_TRY( hipMemsetAsync( sp, 0, MRT_NOALLOC_SCRATCH_WORDS * sizeof( uint32_t ), stream ) );
-    const BatchIO io { in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], hits->prim, hits->t, hits->u, hits->v };
+    const BatchIO io { in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], hits->prim, hits->t, hits->u, hits->v, sc->object_of.p };
     const dim3 block( MRT_TRACE_BLOCK );
     if ( flags == MRT_ANY_HIT )
         hipLaunchKernelGGL( ( trace_batch_kernel<true, false> ), dim3( trace_grid_blocks( trace_batch_kernel<true, false>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, sp + 16, (unsigned long long*)sp );

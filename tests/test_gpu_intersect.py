@@ -399,3 +399,35 @@ def test_tree_deeper_than_sixty_two_levels():
         assert np.array_equal(_bits(t[hit]), _bits(want["t"][hit]))
     abi.hip().mrt_scene_destroy(h)
     del keep
+
+
+def test_object_order_inside_the_library_is_invisible(built, monkeypatch):
+    """mrt_scene_create keeps the objects in the order in which the leaves first reference them; the
+    caller's indices come back from mrt_intersect.  A mesh whose objects were shuffled (so the two
+    orders differ everywhere), spheres, a plane, transforms: hits equal the oracle's on the caller's
+    description, and equal bit for bit what the library returns with the caller's order kept
+    (MRT_OBJECT_ORDER=input); so do the rendered frames."""
+    from raytracer_amd import abi
+    from raytracer_amd.host import render_params
+    sc = _many_transform_scene()
+    abi.host().mrth_shuffle_objects(sc._h, 99)
+    sc.add_ibl_pixels(scenes.synthetic_env(), also_env=True)
+    flat = sc.initKdTree().flatten(1)
+    o, d, tmin, tmax = _rays(flat, 96, 96, 30000, 41)
+    out = []
+    for keep in (False, True):
+        if keep:
+            monkeypatch.setenv("MRT_OBJECT_ORDER", "input")
+        else:
+            monkeypatch.delenv("MRT_OBJECT_ORDER", raising=False)
+        dev = DeviceScene(flat)
+        for any_hit in (False, True):
+            assert _compare(flat, dev, o, d, tmin, tmax, any_hit) > 5000
+        hits = dev.intersect(o, d, tmin, tmax, any_hit=False)
+        img = np.zeros((48, 64, 3), np.float32)
+        dev.render(render_params(64, 48, 2, 2, max_depth=4, seed=5), img)
+        out.append((hits, img))
+        dev.close()
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(_bits(a) if a.dtype == np.float32 else a, _bits(b) if b.dtype == np.float32 else b)
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][1].max() > 0
