@@ -2,6 +2,7 @@
 
   raytracer_amd/libmrt_hip.so   HIP kernels + C-ABI (hipcc, gfx950; cross-compiles without a GPU)
   raytracer_amd/libmrt_host.so  C++ host side (g++), links libmrt_hip.so
+  raytracer_amd/mrt_main        examples/main.cpp: the reference's main.cpp against the host library
   oracle/libmrt_oracle.so       CPU oracle (test infrastructure)
   oracle/_ref/libmrt_ref.so     the reference's own translation units (only where /root/reference exists)
 
@@ -86,6 +87,17 @@ def build_ref(force=False):
     return REF_SO
 
 
+EXAMPLE_BIN = os.path.join(PKG, "mrt_main")
+
+
+def build_example(force=False):
+    """examples/main.cpp, the reference's main.cpp against the host library."""
+    src = os.path.join(ROOT, "examples", "main.cpp")
+    if force or _newer(EXAMPLE_BIN, [src, HOST_SO] + _files(INC, (".h", ".hpp"))):
+        _run(["g++", "-std=c++17", "-O2", "-I" + INC, "-o", EXAMPLE_BIN, src, "-L" + PKG, "-lmrt_host", "-lmrt_hip", "-Wl,-rpath,$ORIGIN"])
+    return EXAMPLE_BIN
+
+
 SANITIZE_BIN = os.path.join(ROOT, "tests", "sanitize", "host_sanitize")
 
 
@@ -105,6 +117,7 @@ def build_sanitize(force=False):
 def build_all(force=False):
     build_hip(force)
     build_host(force)
+    build_example(force)
     build_oracle(force)
     build_ref(force)
 

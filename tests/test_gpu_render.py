@@ -540,3 +540,28 @@ def test_reference_example_scenes(scene_id, w, h, sx, sy):
     check_images(gpu, cpu, sx * sy)
     assert rs.paths == crs.paths == w * h * sx * sy
     assert abs(int(rs.rays_closest) - int(crs.rays_closest)) <= 2e-3 * crs.rays_closest
+
+
+def test_cpp_main_renders_scene_18_to_a_png(tmp_path):
+    """examples/main.cpp -- the reference's main.cpp (parseScene(18), renderer init / run / destroy,
+    freeScene; main.cpp:30-41) written against the C++ host API -- run as a program: the PNG it
+    leaves holds the frame HIPRenderer computes through the Python binding, averaged, gamma-encoded and
+    converted to 8 bits as CPURenderer.cpp:64-69 and image.cpp:135-141 do."""
+    import ctypes as C
+    import subprocess
+    from raytracer_amd import build
+    exe = build.EXAMPLE_BIN
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    w, h, sx, sy = 150, 100, 4, 2
+    name = str(tmp_path / "frame")
+    r = subprocess.run([exe, "18", str(w), str(h), str(sx), str(sy), name, scenes.ASSETS], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "Rendering took" in r.stdout and "Mrays/s" in r.stdout, r.stdout[-2000:]
+    ww, hh = C.c_uint32(), C.c_uint32()
+    px = np.zeros((h, w, 3), np.float32)
+    assert abi.host().mrth_load_image((name + ".png").encode(), C.byref(ww), C.byref(hh), px.ctypes.data_as(abi.f32p), px.size) == 0
+    assert (ww.value, hh.value) == (w, h)
+    got = np.rint(px * 255.0).astype(np.int32)
+    total, _, _ = scenes.parse_scene(18, w, h).hip_render(w, h, sx, sy, max_depth=5, seed=1)
+    want = np.clip((np.float32(255.0) * np.power(total / np.float32(sx * sy), np.float32(1.0 / 2.2))).astype(np.int32), 0, 255)
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
+    assert got.std() > 10  # a picture, not a constant
