@@ -10,7 +10,7 @@ from raytracer_amd.host import DeviceScene, render_params
 name = sys.argv[1]
 sx, sy = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (16, 16)
 W, H = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1920, 1080)
-sc = getattr(scenes, name)(W, H)
+sc = scenes.parse_scene(int(name[5:]), W, H) if name.startswith("scene") else getattr(scenes, name)(W, H)
 tree = sc.initKdTree()
 dev = DeviceScene(tree.flatten(1))
 img = torch.zeros((H, W, 3), device="cuda")
