@@ -32,7 +32,7 @@ class Transform:
         self.ops = []  # the operations applied so far, in order (lets a test replay them elsewhere)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and abi is not None and getattr(abi, "host", None):  # not during interpreter shutdown
             abi.host().mrth_transform_free(self._h)
             self._h = None
 
@@ -86,7 +86,7 @@ class Scene:
         return xf._h
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and abi is not None and getattr(abi, "host", None):  # not during interpreter shutdown
             abi.host().mrth_scene_free(self._h)
             self._h = None
 
@@ -219,7 +219,7 @@ class KdTree:
             raise MrtError(abi.host().mrth_last_error().decode())
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and abi is not None and getattr(abi, "host", None):  # not during interpreter shutdown
             abi.host().mrth_tree_free(self._h)
             self._h = None
 
@@ -271,7 +271,7 @@ class FlatScene:
         self.depth = abi.host().mrth_flat_depth(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and abi is not None and getattr(abi, "host", None):  # not during interpreter shutdown
             abi.host().mrth_flat_free(self._h)
             self._h = None
 
@@ -300,7 +300,7 @@ class DeviceScene:
         self._h = h
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and abi is not None and getattr(abi, "hip", None):  # not during interpreter shutdown
             abi.hip().mrt_scene_destroy(self._h)
             self._h = None
 
