@@ -14,11 +14,17 @@
 //     strictly nearer, and the search ends at the first leaf that produced a hit;
 //   - shadow (any-hit) rays stop at the first hit on a non-emissive primitive; hits on emissive
 //     primitives are ignored but still shrink tmax for the rest of that leaf;
-//   - planes live outside the tree.  The reference tests them after the tree, as a closest-hit ray
-//     over the ORIGINAL interval whose upper end is the tree hit distance if there was one; a plane
-//     replaces a tree hit only if strictly nearer.  That outcome does not depend on the order, so
-//     here the planes are tested when a ray is fetched (nearest plane, first one on ties; for
-//     any-hit rays the first accepted plane) and merged with the tree result when the ray retires.
+//   - planes live outside the tree.  The reference tests them after the tree (kdtree.cpp:588-611), in
+//     list order, each accepted plane shrinking the interval for the next, as a closest-hit ray over
+//     [0, D]: D is the tree hit distance if there was one -- even where that lies beyond the ray's own
+//     tmax, which happens after a split distance came out NaN (an axis-parallel ray that starts in
+//     the split plane: 0 / 0) -- and the ray's own tmax otherwise; a plane replaces the tree hit only
+//     if strictly nearer.  The outcome is the first of the nearest planes if that one lies within D,
+//     so here the planes are tested when a ray is fetched (a closest-hit ray: the nearest plane at
+//     any distance, the first one on ties; an any-hit ray, which never reaches the planes once the
+//     tree produced an occluder: the first plane accepted within its own interval) and D is applied
+//     when the ray retires.  (One case is not reproduced: a plane whose distance is NaN listed after
+//     a plane beyond D is a hit for the reference and none here.)
 //
 // Execution model: streaming traversal.  The waves draw chunks (MRT_CHUNK rays) of the ray list from
 // counters (one per eighth of the list, see trace_stream) and every
@@ -397,10 +403,11 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                         *out_lds = m;
                     }
                     put_xr( o, d );
-                    // planes (kdtree.cpp:563-611), over the original interval: nearest one, the
-                    // first on ties; an any-hit ray stops at the first accepted plane
+                    // planes (kdtree.cpp:563-611): an any-hit ray stops at the first one accepted within
+                    // its interval; a closest-hit ray takes the nearest one, the first on ties (how far
+                    // it may lie is known when the ray retires)
                     has_pl      = false;
-                    float btmax = ray_tmax;
+                    float btmax = ANY ? ray_tmax : __uint_as_float( 0x7f800000u );
                     if ( STATS ) pl_tests = s.n_out;
                     for ( uint32_t k = 0; k < s.n_out; k++ ) {
                         const uint32_t po = s.out_of_tree[k];
@@ -449,11 +456,13 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                         if ( STATS ) st.tests += pl_tests;
                         DHit h;
                         h.prim = -1, h.t = ray_tmax, h.u = h.v = 0.f, h.outside = 0;
+                        bool found = has_pl;
                         if ( !BOOL_ONLY && has_pl ) {
                             const v4f r = *pl_lds;
-                            h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
+                            found       = ANY | !( r.y > ray_tmax ); // Plane::intersect rejects t > tmax
+                            if ( found ) h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
                         }
-                        io.store( tag, has_pl, h );
+                        io.store( tag, found, h );
                     }
                 }
             }
@@ -538,9 +547,12 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 outside = !( det < 0.f );
             }
             else { hit = sphere_test( s, xf_lds, xf, origin, dir, o, d, a, tmax, t, outside ); }
-            // accepted hits shrink the interval whether or not they are kept
+            // Accepted hits shrink the interval whether or not they are kept.  For a closest-hit ray
+            // an accepted hit that is not kept has a distance that compares EQUAL to the kept one
+            // (t <= tmax and !(t < tmax)), so tmax stays the kept hit's own distance, which is what the
+            // reference reports (kdtree.cpp:547): the two differ when one is -0 and the other +0.
             const bool keep = hit & ( ANY ? !( flags & MRT_PRIM_EMISSIVE ) : ( !has | ( t < tmax ) ) );
-            tmax            = hit ? t : tmax;
+            tmax            = ( ANY ? hit : keep ) ? t : tmax;
             if ( !BOOL_ONLY && keep ) {
                 v2f m;
                 m.x = __uint_as_float( obj | ( outside ? 0x80000000u : 0u ) ), m.y = u;
@@ -586,8 +598,10 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 h.outside = has ? __float_as_uint( rec.x ) >> 31 : 0u;
                 if ( has_pl ) {
                     const v4f r = *pl_lds;
-                    // a plane replaces a tree hit only if strictly nearer (never for an any-hit ray)
-                    if ( !has || ( !ANY && r.y < h.t ) ) {
+                    // A closest-hit ray: the plane must lie within the tree hit distance or, without a
+                    // tree hit, within the tmax the ray came with (h.t in both cases), and replaces a
+                    // tree hit only if strictly nearer.  An any-hit ray: only without a tree hit.
+                    if ( ANY ? !has : ( has ? r.y < h.t : !( r.y > h.t ) ) ) {
                         h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
                         found  = true;
                     }

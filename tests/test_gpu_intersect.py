@@ -431,3 +431,28 @@ def test_object_order_inside_the_library_is_invisible(built, monkeypatch):
     for a, b in zip(out[0][0], out[1][0]):
         assert np.array_equal(_bits(a) if a.dtype == np.float32 else a, _bits(b) if b.dtype == np.float32 else b)
     assert np.array_equal(out[0][1], out[1][1]) and out[0][1].max() > 0
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_scenes_with_ties_against_the_oracle(built, seed):
+    """Differential test on seeded random scenes built to produce ties (tests/fuzz_scenes.py):
+    mrt_intersect against the oracle, closest and shadow rays, both node layouts, hit ids, distances
+    and barycentrics bit for bit, and the traversal counters."""
+    from tests import fuzz_scenes
+    sc = fuzz_scenes.make(seed)
+    tree = sc.initKdTree(1 + seed % 4)
+    for layout in (0, 1):
+        flat = tree.flatten(layout)
+        dev = DeviceScene(flat)
+        o, d, tmin, tmax = fuzz_scenes.rays(flat, seed)
+        for any_hit in (False, True):
+            assert _compare(flat, dev, o, d, tmin, tmax, any_hit) > 500
+        want, ws = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, False, stats=True)
+        prim, t, u, v, gs = dev.intersect(o, d, tmin, tmax, stats=True)
+        kinds = np.ctypeslib.as_array(flat.desc.contents.obj_kind, shape=(sc.n_objects,))
+        tri = (prim >= 0) & (kinds[np.maximum(prim, 0)] == 3)  # the scenes' texture coordinates make the reference's u, v the barycentrics
+        assert tri.sum() > 300
+        # equal as numbers: the reference's interpolation u * 1 + v * 0 + w * 0 turns a barycentric of -0 into +0
+        assert np.array_equal(u[tri], want["u"][tri]) and np.array_equal(v[tri], want["v"][tri])
+        assert (gs.inner, gs.leaves, gs.refs, gs.prim_tests) == (ws.inner, ws.leaves, ws.refs, ws.prim_tests)
+        dev.close()

@@ -410,3 +410,29 @@ def test_reference_side_adapter_flattens_textures(built):
     xd = np.ctypeslib.as_array(C.cast(d.texels, abi.u32p), shape=(d.n_texels,))
     assert np.array_equal(xa, xd)
     lib.ref_adapter_free(h_)
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_live_reference_random_scenes_with_ties(built, seed):
+    """Container only: on the seeded random scenes of tests/fuzz_scenes.py (duplicates, coplanar
+    overlaps, grid-aligned vertices, slivers, emissive primitives, transformed spheres, planes) the
+    product's tree equals the tree the reference's initKdTree builds from the same objects, and the
+    oracle's hits equal the reference's intersectKdTree bit for bit, closest and shadow rays."""
+    from tests import fuzz_scenes
+    sc = fuzz_scenes.make(seed)
+    tree = sc.initKdTree(1 + seed % 3)
+    flat = tree.flatten(0)
+    rs = orc.RefScene(flat.desc, orc.xf_ops_for(flat, sc))
+    assert orc.tree_digest(orc.canonical_from_dump(rs.dump())) == orc.tree_digest(orc.canonical_from_abi(*flat.nodes()))
+    o, d, tmin, tmax = fuzz_scenes.rays(flat, seed)
+    for shadow in (False, True):
+        a = rs.intersect(o, d, tmin, tmax, shadow)
+        b = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, shadow)
+        h = a["hit"] == 1
+        assert np.array_equal(a["hit"], b["hit"])
+        assert np.array_equal(bits(a["t"])[h], bits(b["t"])[h])
+        if not shadow:
+            assert np.array_equal(a["prim"][h], b["prim"][h])
+            assert np.array_equal(bits(a["u"])[h], bits(b["u"])[h]) and np.array_equal(bits(a["v"])[h], bits(b["v"])[h])
+            assert np.array_equal(a["outside"][h], b["outside"][h])
