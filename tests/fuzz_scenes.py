@@ -68,3 +68,40 @@ def rays(flat, seed, n_random=6000):
     tmax[::7] = (rng.random(len(tmax[::7])) * 6).astype(np.float32)
     tmin[3::9] = (rng.random(len(tmin[3::9])) * 2).astype(np.float32)
     return np.ascontiguousarray(o), np.ascontiguousarray(d), tmin, tmax
+
+
+def rays_hard(flat, seed, n=12000):
+    """Rays aimed at the places where ties and degenerate arithmetic live: from vertices, edge
+    midpoints and centroids of the scene's (untransformed) triangles, towards other vertices (through
+    shared vertices and along edges), along the axes with -0.0 components, with empty, zero-length and
+    inverted intervals."""
+    rng = np.random.default_rng(seed + 5000)
+    d_ = flat.desc.contents
+    m = d_.n_objects
+    kinds = np.ctypeslib.as_array(d_.obj_kind, shape=(m,))
+    xf = np.ctypeslib.as_array(d_.obj_transform, shape=(m,))
+    tri = np.ctypeslib.as_array(d_.tri_p, shape=(m, 9))[(kinds == 3) & (xf == 0)].reshape(-1, 3, 3).astype(np.float32)
+    verts = tri.reshape(-1, 3)
+    mids = ((tri[:, 0] + tri[:, 1]) * np.float32(0.5))
+    cents = ((tri[:, 0] + tri[:, 1] + tri[:, 2]) / np.float32(3))
+    pts = np.concatenate([verts, mids, cents]).astype(np.float32)
+    a = pts[rng.integers(0, len(pts), n)]
+    b = pts[rng.integers(0, len(pts), n)]
+    d = (b - a).astype(np.float32)
+    axis = np.zeros((n, 3), np.float32)
+    axis[np.arange(n), rng.integers(0, 3, n)] = rng.choice(np.array([-1.0, 1.0], np.float32), n)
+    use_axis = rng.random(n) < 0.35
+    d[use_axis] = axis[use_axis]
+    d[(d == 0).all(axis=1)] = np.float32([0, 0, 1])
+    neg0 = rng.random((n, 3)) < 0.3
+    d = np.where((d == 0) & neg0, np.float32(-0.0), d).astype(np.float32)
+    back = rng.random(n) < 0.5            # half of the rays start before the point and pass through it
+    o = np.where(back[:, None], a - d * np.float32(0.5), a).astype(np.float32)
+    tmin, tmax = np.zeros(n, np.float32), np.full(n, 1e5, np.float32)
+    k = rng.random(n)
+    tmax[k < 0.1] = 0.0
+    tmax[(k >= 0.1) & (k < 0.25)] = (rng.random(int(((k >= 0.1) & (k < 0.25)).sum())) * 1.5).astype(np.float32)
+    tmin[(k >= 0.25) & (k < 0.35)] = (rng.random(int(((k >= 0.25) & (k < 0.35)).sum())) * 1.5).astype(np.float32)
+    inv = (k >= 0.35) & (k < 0.4)
+    tmin[inv], tmax[inv] = 2.0, 1.0
+    return np.ascontiguousarray(o), np.ascontiguousarray(d), tmin, tmax

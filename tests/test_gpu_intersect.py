@@ -445,6 +445,8 @@ def test_random_scenes_with_ties_against_the_oracle(built, seed):
         flat = tree.flatten(layout)
         dev = DeviceScene(flat)
         o, d, tmin, tmax = fuzz_scenes.rays(flat, seed)
+        o2, d2, tmin2, tmax2 = fuzz_scenes.rays_hard(flat, seed)  # from vertices, along edges, -0.0 components, empty intervals
+        o, d, tmin, tmax = np.concatenate([o, o2]), np.concatenate([d, d2]), np.concatenate([tmin, tmin2]), np.concatenate([tmax, tmax2])
         for any_hit in (False, True):
             assert _compare(flat, dev, o, d, tmin, tmax, any_hit) > 500
         want, ws = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, False, stats=True)

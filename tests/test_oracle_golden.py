@@ -426,6 +426,8 @@ def test_live_reference_random_scenes_with_ties(built, seed):
     rs = orc.RefScene(flat.desc, orc.xf_ops_for(flat, sc))
     assert orc.tree_digest(orc.canonical_from_dump(rs.dump())) == orc.tree_digest(orc.canonical_from_abi(*flat.nodes()))
     o, d, tmin, tmax = fuzz_scenes.rays(flat, seed)
+    o2, d2, tmin2, tmax2 = fuzz_scenes.rays_hard(flat, seed)  # from vertices, along edges, -0.0 components, empty intervals
+    o, d, tmin, tmax = np.concatenate([o, o2]), np.concatenate([d, d2]), np.concatenate([tmin, tmin2]), np.concatenate([tmax, tmax2])
     for shadow in (False, True):
         a = rs.intersect(o, d, tmin, tmax, shadow)
         b = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, shadow)

@@ -15,6 +15,8 @@ for seed in range(first, first + count):
     kinds = np.ctypeslib.as_array(d_.obj_kind, shape=(d_.n_objects,))
     dev = DeviceScene(flat)
     o, d, tmin, tmax = fuzz_scenes.rays(flat, seed, n_random=20000)
+    o2, d2, tmin2, tmax2 = fuzz_scenes.rays_hard(flat, seed)
+    o, d, tmin, tmax = np.concatenate([o, o2]), np.concatenate([d, d2]), np.concatenate([tmin, tmin2]), np.concatenate([tmax, tmax2])
     for any_hit in (False, True):
         want, ws = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, any_hit, stats=True)
         prim, t, u, v, gs = dev.intersect(o, d, tmin, tmax, any_hit=any_hit, stats=True)
