@@ -105,3 +105,55 @@ def rays_hard(flat, seed, n=12000):
     inv = (k >= 0.35) & (k < 0.4)
     tmin[inv], tmax[inv] = 2.0, 1.0
     return np.ascontiguousarray(o), np.ascontiguousarray(d), tmin, tmax
+
+
+def make_shaded(seed, min_roughness=0.0):
+    """A random scene for the shading loop: meshes of random Cook-Torrance materials (all three types,
+    roughness down to 0, checker textures), spheres, a floor plane, and lights drawn from: a synthetic
+    environment map, sphere lights, triangle lights; thin-lens camera."""
+    from raytracer_amd import abi, scenes
+    rng = np.random.default_rng(seed + 9000)
+    sc = Scene()
+    mats = []
+    for i in range(int(rng.integers(3, 9))):
+        typ = int(rng.choice([abi.MRT_MAT_DIFFUSE, abi.MRT_MAT_SPECULAR, abi.MRT_MAT_TRANSPARENT], p=[0.5, 0.3, 0.2]))
+        rough = max(float(rng.choice([0.0, 0.002, 0.05, 0.3, 0.8, 1.0])), min_roughness)
+        m = sc.CreateMaterial(typ, albedo=tuple(float(x) for x in rng.random(3)), roughness=rough, metalness=float(rng.choice([0.0, 0.1, 1.0])),
+                              ior=float(1.0 + rng.random()))
+        if typ != abi.MRT_MAT_TRANSPARENT and rng.random() < 0.3:
+            sc.set_checker(m, tuple(float(x) for x in rng.random(3)), tuple(float(x) for x in rng.random(3)), Transform().scale(0.25, 0.25, 1))
+        mats.append(m)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), 3)
+    uv = np.array([0, 0, 1, 0, 0, 1], np.float32)
+    for i in range(int(rng.integers(30, 200))):
+        c = (rng.random(3) * 4 - 2).astype(np.float32)
+        p = (np.tile(c, 3) + (rng.random(9) - 0.5).astype(np.float32) * np.float32(1.6)).astype(np.float32)
+        e1, e2 = p[3:6] - p[0:3], p[6:9] - p[0:3]
+        fn = np.cross(e1, e2)
+        fn = fn / max(np.linalg.norm(fn), 1e-20)
+        n3 = np.tile(fn.astype(np.float32), 3) if rng.random() < 0.7 else nrm
+        sc.add_triangle(p, n3, tuple(float(x) for x in fn), uv, Transform(), mats[int(rng.integers(0, len(mats)))])
+    for i in range(int(rng.integers(1, 6))):
+        t = Transform().scale(*(0.3 + 0.5 * rng.random(3))).translate(tuple(float(x) for x in (rng.random(3) * 3 - 1.5)))
+        sc.add_sphere(t, mats[int(rng.integers(0, len(mats)))])
+    sc.add_plane(Transform().scale(6, 6, 1).rotate((1, 0, 0), -90.0).translate((0, -2.2, 0)), mats[0])
+    lights = int(rng.integers(1, 8))  # bit 0: environment, bit 1: sphere lights, bit 2: triangle light
+    if lights & 1:
+        sc.add_ibl_pixels(scenes.synthetic_env(seed=seed), also_env=True)
+    if lights & 2:
+        for i in range(int(rng.integers(1, 4))):
+            e = float(rng.choice([5.0, 40.0, 300.0]))
+            m = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(1, 1, 1), emission=(e, e, e))
+            r = float(rng.choice([0.05, 0.2, 0.6]))
+            t = Transform().scale(r, r, r).translate(tuple(float(x) for x in (rng.random(3) * 3 - 1.5 + np.array([0, 2.0, 0]))))
+            sc.add_sphere(t, m)
+            sc.add_sphere_light(t, m, (e, e, e))
+    if lights & 4:
+        e = 25.0
+        m = sc.CreateMaterial(abi.MRT_MAT_DIFFUSE, albedo=(1, 1, 1), emission=(e, e, e))
+        p = np.array([-0.6, 2.4, -0.6, 0.6, 2.4, -0.6, 0.0, 2.4, 0.7], np.float32)
+        n3 = np.tile(np.array([0, -1, 0], np.float32), 3)
+        sc.add_triangle(p, n3, (0, -1, 0), uv, Transform(), m)
+        sc.add_triangle_light(p, n3, (0, -1, 0), Transform(), m, (e, e, e))
+    sc.setSimpleCamera((0.4, 0.6, 6.5), (0, 0, 0), (0, 1, 0), 50.0, 64, 48, float(rng.choice([0.0, 0.05])), 6.5)
+    return sc

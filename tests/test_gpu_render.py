@@ -565,3 +565,36 @@ def test_cpp_main_renders_scene_18_to_a_png(tmp_path):
     want = np.clip((np.float32(255.0) * np.power(total / np.float32(sx * sy), np.float32(1.0 / 2.2))).astype(np.int32), 0, 255)
     assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
     assert got.std() > 10  # a picture, not a constant
+
+
+@pytest.mark.parametrize("min_roughness", [0.05, 0.0])
+def test_random_shaded_scenes_against_the_oracle(min_roughness):
+    """Seeded random scenes for the shading loop (tests/fuzz_scenes.py make_shaded: every material
+    type, checker textures, spheres, a floor plane, environment / sphere / triangle lights in every
+    combination, thin lens).  With roughness >= 0.05 the usual tolerances hold.  With the full
+    roughness range, 0.002 makes the Beckmann exponent (cos^2 - 1) / (alpha^2 cos^2) amplify a
+    last-ulp difference of sinf/cosf in the sampled half vector to about a percent of that sample,
+    so the pixel fraction is 98 %; and roughness 0 makes the reference's expressions divide 0 by 0:
+    the pixels that are not finite must then be the same pixels, not finite in the same way."""
+    from tests import fuzz_scenes
+    W, H = 64, 48
+    for seed in (0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 14):
+        sc = fuzz_scenes.make_shaded(seed, min_roughness)
+        flat = sc.initKdTree(2).flatten(1)
+        dev = DeviceScene(flat)
+        p = render_params(W, H, 2, 2, max_depth=6, seed=seed + 1)
+        gpu = np.zeros((H, W, 3), np.float32)
+        rs = dev.render(p, gpu)
+        cpu, crs, _, _ = orc.oracle_render(flat.desc, p, 0, threads=16)
+        dev.close()
+        assert np.array_equal(np.isnan(gpu), np.isnan(cpu)), seed
+        assert np.array_equal(np.isposinf(gpu), np.isposinf(cpu)) and np.array_equal(np.isneginf(gpu), np.isneginf(cpu)), seed
+        ok = np.isfinite(cpu).all(axis=2)
+        if min_roughness > 0:
+            assert ok.all(), seed
+        g, c = gpu[ok] / 4, cpu[ok] / 4
+        r = rel_mse(g, c)
+        frac = float(((np.abs(g - c) / (np.abs(c) + 1e-3)).max(axis=1) <= PIXEL_REL_TOL).mean())
+        assert r <= REL_MSE_TOL, "seed %d relMSE %g" % (seed, r)
+        assert frac >= (PIXEL_FRACTION if min_roughness > 0 else 0.98), "seed %d: only %.4f of the pixels within %g" % (seed, frac, PIXEL_REL_TOL)
+        assert rs.paths == crs.paths == W * H * 4
