@@ -15,6 +15,7 @@ MRT_OK = 0
 MRT_SPHERE, MRT_PLANE, MRT_TRIANGLE = 1, 2, 3
 MRT_MAT_DIFFUSE, MRT_MAT_SPECULAR, MRT_MAT_TRANSPARENT = 0, 1, 2
 MRT_LIGHT_SHAPE, MRT_LIGHT_IBL = 0, 1
+MRT_TEX_IMAGE, MRT_TEX_CHECKER = 0, 1
 MRT_BUF_HOST, MRT_BUF_DEVICE = 0, 1
 MRT_CLOSEST_HIT, MRT_ANY_HIT = 0, 1
 MRT_RENDER_TRACE_STATS = 1

@@ -250,6 +250,11 @@ MRT_DEV V3 texture_value( const DShade& s, int32_t ti, float u, float v ) {
     }
     int u2     = (int)( ux * (float)( t.w - 1 ) );
     int v2     = (int)( vy * (float)( t.h - 1 ) );
+    // ux, vy are in [0, 1] unless a texture coordinate is beyond the int range (or infinite), where
+    // the reference's conversions are undefined; the clamps change no defined result and keep the
+    // read inside the image
+    u2         = min( max( u2, 0 ), (int)t.w - 1 );
+    v2         = min( max( v2, 0 ), (int)t.h - 1 );
     uint64_t p = (uint64_t)( t.h - v2 - 1 ) * t.w + u2;
     return ld3( s.texels + t.offset + 3 * p );
 }

@@ -252,6 +252,7 @@ mrt_status xcd_mask_for_device( int device, uint32_t* mask_out ) {
 } // namespace
 
 static mrt_status upload_shading( const mrt_scene_desc* d, mrt_scene* s ); // render_host.inc
+static mrt_status validate_shading( const mrt_scene_desc* d );
 namespace {
 void free_workspace( RenderWorkspace& w );
 mrt_status scratch_for_device( int device, uint32_t** out ); // with mrt_intersect_noalloc
@@ -311,7 +312,10 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     for ( uint32_t i = 0; i < d->n_objects; i++ ) {
         if ( d->obj_material[i] >= d->n_materials ) return fail( MRT_ERR_INVALID, "object material out of range" );
         if ( d->obj_transform[i] >= d->n_transforms ) return fail( MRT_ERR_INVALID, "object transform out of range" );
+        if ( d->obj_kind[i] != MRT_TRIANGLE && d->obj_kind[i] != MRT_SPHERE && d->obj_kind[i] != MRT_PLANE ) return fail( MRT_ERR_UNSUPPORTED, "unsupported object kind" );
     }
+    vs = validate_shading( d );
+    if ( vs != MRT_OK ) return vs;
 
     // The library keeps the objects in the order in which the leaves first reference them (leaves in
     // node order, i.e. depth-first below the top of the tree), so that the primitive records a ray

@@ -269,6 +269,116 @@ def test_scene_create_rejects_malformed_descriptions(built):
     assert lib.mrt_scene_create(None, 0, C.byref(h)) == 1
 
 
+def _copy_array(d, field, ctype, count):
+    arr = (ctype * max(count, 1))()
+    src = getattr(d, field)
+    if count and src:
+        C.memmove(arr, src, C.sizeof(ctype) * count)
+    setattr(d, field, C.cast(arr, type(src)))
+    return arr
+
+
+def test_scene_create_validates_everything_a_kernel_indexes_with(built):
+    """Materials, textures, lights, the environment and object kinds are checked on the host, before
+    any device call; then 400 seeded corruptions of the index-carrying tables of a valid description
+    (tree nodes, leaf references, out-of-tree list, per-object indices, material / texture / light
+    records): every call returns a status -- malformed, unsupported, or, being valid still, the
+    missing device (success on a machine with a GPU) -- and none crashes."""
+    from tests import fuzz_scenes
+    lib = abi.hip()
+    for seed in range(64):  # the first scene with an environment, a shape light and a texture
+        sc = fuzz_scenes.make_shaded(seed)
+        flat = sc.initKdTree(2).flatten(1)
+        desc = flat.desc.contents
+        if desc.n_textures >= 1 and desc.env_light >= 0 and any(desc.lights[i].kind == abi.MRT_LIGHT_SHAPE for i in range(desc.n_lights)):
+            break
+    else:
+        raise AssertionError("no seed gives a scene with all three")
+    h = C.c_void_p()
+
+    def try_create(mutate):
+        d = abi.SceneDesc()
+        C.memmove(C.byref(d), flat.desc, C.sizeof(abi.SceneDesc))
+        keep = mutate(d)
+        st = lib.mrt_scene_create(C.byref(d), 0, C.byref(h))
+        if st == 0:
+            lib.mrt_scene_destroy(h)
+        return st, lib.mrt_last_error().decode(), keep
+
+    valid = (0, 2)  # created, or no device
+    assert try_create(lambda d: None)[0] in valid
+
+    def edit(field, ctype, count_field, index, attr, value):
+        def mutate(d):
+            arr = _copy_array(d, field, ctype, getattr(d, count_field))
+            if attr is None:
+                arr[index] = value
+            else:
+                setattr(arr[index], attr, value(d) if callable(value) else value)
+            return arr
+        return mutate
+
+    shape_light = next(i for i in range(desc.n_lights) if desc.lights[i].kind == abi.MRT_LIGHT_SHAPE)
+    textured = next(i for i in range(desc.n_materials) if desc.materials[i].texture >= 0)
+    for mutate, status, text in [
+        (edit("materials", abi.Material, "n_materials", textured, "texture", lambda d: d.n_textures), 1, "material texture"),
+        (edit("materials", abi.Material, "n_materials", 0, "type", 3), 1, "material type"),
+        (edit("textures", abi.Texture, "n_textures", 0, "kind", 7), 1, "texture kind"),
+        (edit("lights", abi.Light, "n_lights", shape_light, "kind", 9), 1, "light kind"),
+        (edit("lights", abi.Light, "n_lights", shape_light, "shape_kind", abi.MRT_PLANE), 1, "triangle or a sphere"),
+        (edit("lights", abi.Light, "n_lights", shape_light, "transform", lambda d: d.n_transforms), 1, "light transform"),
+        (lambda d: setattr(d, "env_light", d.n_lights), 1, "env_light out of range"),
+        (lambda d: setattr(d, "env_light", shape_light), 1, "must name an IBL"),
+        (lambda d: setattr(d, "env_width", 0), 1, "without environment pixels"),
+        (lambda d: setattr(d, "env_width", 1 << 16), 4, "too large"),
+        (edit("obj_kind", C.c_uint8, "n_objects", 5, None, 4), 4, "object kind"),  # CUBE (geometry.h:5)
+        (edit("obj_transform", C.c_uint32, "n_objects", 5, None, 1 << 20), 1, "object transform"),
+    ]:
+        st, msg, _ = try_create(mutate)
+        assert st == status and text in msg, (st, msg, text)
+
+    def image_texture(width, height, offset):
+        def mutate(d):
+            arr = _copy_array(d, "textures", abi.Texture, d.n_textures)
+            arr[0].kind, arr[0].width, arr[0].height, arr[0].texel_offset = abi.MRT_TEX_IMAGE, width, height, offset
+            texels = (C.c_float * 48)()
+            d.texels, d.n_texels = C.cast(texels, type(d.texels)), 48
+            return arr, texels
+        return mutate
+    assert try_create(image_texture(4, 4, 0))[0] in valid
+    for w, hgt, off in [(4, 4, 3), (5, 4, 0), (0, 4, 0), (4, 4, 2 ** 64 - 3), (65536, 65536, 0), (2 ** 32 - 1, 2 ** 32 - 1, 0)]:
+        st, msg, _ = try_create(image_texture(w, hgt, off))
+        assert st == 1 and "texel pool" in msg, (w, hgt, off, st, msg)
+
+    rng = np.random.default_rng(5)
+    tables = [("nodes", C.c_uint32, lambda d: 2 * d.n_nodes), ("refs", C.c_uint32, lambda d: d.n_refs),
+              ("out_of_tree", C.c_uint32, lambda d: d.n_out_of_tree), ("obj_material", C.c_uint32, lambda d: d.n_objects),
+              ("obj_transform", C.c_uint32, lambda d: d.n_objects), ("obj_kind", C.c_uint8, lambda d: d.n_objects),
+              ("materials", C.c_uint32, lambda d: d.n_materials * C.sizeof(abi.Material) // 4),
+              ("textures", C.c_uint32, lambda d: d.n_textures * C.sizeof(abi.Texture) // 4),
+              ("lights", C.c_uint32, lambda d: d.n_lights * C.sizeof(abi.Light) // 4)]
+    seen = set()
+    for trial in range(400):
+        field, ctype, words = tables[trial % len(tables)]
+
+        def corrupt(d):
+            n = words(d)
+            arr = (ctype * max(n, 1))()
+            src = getattr(d, field)
+            C.memmove(arr, src, C.sizeof(ctype) * n)
+            for _ in range(int(rng.integers(1, 4))):
+                k = int(rng.integers(0, n))
+                how = int(rng.integers(0, 3))
+                bits = 8 * C.sizeof(ctype)
+                arr[k] = [int(arr[k]) ^ (1 << int(rng.integers(0, bits))), int(rng.integers(0, 1 << bits)), (1 << bits) - 1][how]
+            setattr(d, field, C.cast(arr, type(src)))
+            return arr
+        st, msg, _ = try_create(corrupt)
+        assert st in (0, 1, 2, 4), (trial, field, st, msg)
+        seen.add(st)
+    assert 1 in seen and (0 in seen or 2 in seen)
+
+
 def test_product_path_fails_loudly_without_a_gpu(built):
     """No CPU fallback: on a machine without a HIP device the scene cannot be created and the
     renderer raises; nothing is routed through the oracle."""
