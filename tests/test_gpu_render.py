@@ -598,3 +598,44 @@ def test_random_shaded_scenes_against_the_oracle(min_roughness):
         assert r <= REL_MSE_TOL, "seed %d relMSE %g" % (seed, r)
         assert frac >= (PIXEL_FRACTION if min_roughness > 0 else 0.98), "seed %d: only %.4f of the pixels within %g" % (seed, frac, PIXEL_REL_TOL)
         assert rs.paths == crs.paths == W * H * 4
+
+
+def test_render_rejects_bad_parameters():
+    """mrt_render's argument checks (status codes, nothing launched): empty image or grid, sample and
+    row ranges outside the grid, a depth beyond the per-bounce tables (also one that would wrap),
+    a sample grid whose product does not fit 32 bits, a scene without a camera."""
+    import ctypes as C
+    lib = abi.hip()
+    sc = scenes.cornell(16, 16)
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    img = np.zeros((16, 16, 3), np.float32)
+
+    def status(**kw):
+        args = dict(width=16, height=16, spp_x=2, spp_y=2)
+        args.update(kw)
+        raw = {k: args.pop(k) for k in ("sample_end", "row_end") if k in args}
+        p = render_params(**args)
+        for k, v in raw.items():
+            setattr(p, k, v)
+        st = lib.mrt_render(dev._h, C.byref(p), img.ctypes.data_as(C.c_void_p), abi.MRT_BUF_HOST, None, None)
+        return st, lib.mrt_last_error().decode()
+
+    assert status()[0] == 0
+    for kw, st, text in [(dict(width=0), 1, "empty"), (dict(spp_y=0), 1, "empty"),
+                         (dict(sample_end=5), 1, "sample range"), (dict(sample_begin=3, sample_end=2), 1, "sample range"),
+                         (dict(row_end=17), 1, "row range"), (dict(row_begin=9, row_end=8), 1, "row range"),
+                         (dict(max_depth=63), 4, "max_depth"), (dict(max_depth=2 ** 32 - 1), 4, "max_depth"),
+                         (dict(spp_x=65536, spp_y=65536, sample_end=1), 4, "sample grid")]:
+        got, msg = status(**kw)
+        assert got == st and text in msg, (kw, got, msg)
+    assert not img.any() or np.isfinite(img).all()
+    dev.close()
+    sc2 = scenes.cornell(16, 16)
+    flat2 = sc2.initKdTree().flatten(1)
+    flat2.desc.contents.has_camera = 0
+    dev2 = DeviceScene(flat2)
+    p = render_params(16, 16, 1, 1)
+    assert lib.mrt_render(dev2._h, C.byref(p), img.ctypes.data_as(C.c_void_p), abi.MRT_BUF_HOST, None, None) == 1
+    assert "camera" in lib.mrt_last_error().decode()
+    dev2.close()
