@@ -102,15 +102,28 @@ SANITIZE_BIN = os.path.join(ROOT, "tests", "sanitize", "host_sanitize")
 
 
 def build_sanitize(force=False):
-    """The host library's sources and tests/sanitize/host_sanitize.cpp compiled together with
-    AddressSanitizer + UndefinedBehaviorSanitizer (host code only; GPU sanitizers are not available)."""
+    """The host library's sources, the host side of the HIP library (mrt_hip.hip: the C-ABI's
+    validation and set-up code) and tests/sanitize/host_sanitize.cpp compiled with AddressSanitizer +
+    UndefinedBehaviorSanitizer into one executable.  Host code only: GPU sanitizers are not available,
+    so the .hip file gets its -fsanitize options through -Xarch_host.  Everything is built by the
+    ROCm clang so that one sanitizer runtime serves all objects."""
     host_dir = os.path.join(CSRC, "host")
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
     srcs = _files(host_dir, (".cpp",)) + [os.path.join(ROOT, "tests", "sanitize", "host_sanitize.cpp")]
-    deps = srcs + _files(host_dir, (".hpp",)) + _files(INC, (".h", ".hpp")) + [HIP_SO]
+    hip_deps = [f for f in _files(CSRC, (".hip", ".hpp", ".inc")) if os.sep + "host" + os.sep not in f]
+    deps = srcs + hip_deps + _files(host_dir, (".hpp",)) + _files(INC, (".h", ".hpp"))
     if force or _newer(SANITIZE_BIN, deps):
-        _run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
-              "-fno-sanitize-recover=undefined", "-fopenmp", "-ffp-contract=off", "-I" + INC, "-I" + host_dir, "-o", SANITIZE_BIN] + srcs +
-             ["-L" + PKG, "-lmrt_hip", "-Wl,-rpath," + PKG])
+        import tempfile
+        san = ["-fsanitize=address", "-fsanitize=undefined", "-fno-sanitize-recover=undefined"]
+        with tempfile.TemporaryDirectory() as tmp:
+            objs = [os.path.join(tmp, "mrt_hip.o")]
+            _run(["hipcc", "--offload-arch=gfx950", "-O1", "-g", "-ffp-contract=off", "-std=c++17"] +
+                 [a for f in san for a in ("-Xarch_host", f)] + ["-I" + INC, "-c", "-o", objs[0], os.path.join(CSRC, "mrt_hip.hip")])
+            for src in srcs:
+                objs.append(os.path.join(tmp, os.path.basename(src)[:-4] + ".o"))
+                _run([clang, "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer"] + san +
+                     ["-fopenmp", "-ffp-contract=off", "-I" + INC, "-I" + host_dir, "-c", "-o", objs[-1], src])
+            _run(["hipcc", "-fno-gpu-sanitize"] + san + ["-fopenmp", "-o", SANITIZE_BIN] + objs + ["-Wl,-rpath,/opt/rocm/lib/llvm/lib"])
     return SANITIZE_BIN
 
 

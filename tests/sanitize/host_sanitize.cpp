@@ -64,6 +64,35 @@ static int mesh_scene( const std::string& assets, const char* obj, float prescal
             flat->nodes[0] = saved;
         }
     }
+    {
+        // seeded corruptions of the tree and the per-object tables: validation reads nothing out of
+        // bounds (a sanitizer report otherwise) and answers with a status every time
+        std::unique_ptr<FlatScene> flat( flatten( scene, tree ) );
+        uint32_t state = 2024u + (uint32_t)expect_objects;
+        auto next      = [&state]() { return state = state * 1664525u + 1013904223u; };
+        for ( int round = 0; round < 120; round++ ) {
+            std::vector<mrt_kdnode> nodes( flat->desc.nodes, flat->desc.nodes + flat->desc.n_nodes );
+            std::vector<uint32_t> refs( flat->desc.refs, flat->desc.refs + flat->desc.n_refs );
+            std::vector<uint32_t> mats( flat->desc.obj_material, flat->desc.obj_material + flat->desc.n_objects );
+            std::vector<uint8_t> kinds( flat->desc.obj_kind, flat->desc.obj_kind + flat->desc.n_objects );
+            for ( int k = 0; k < 3; k++ ) {
+                const uint32_t what = next() >> 8, at = next() >> 4, value = ( next() & 1u ) ? next() : ( 1u << ( next() >> 27 ) );
+                switch ( what % 5u ) {
+                case 0: nodes[at % nodes.size()].w0 ^= value; break;
+                case 1: nodes[at % nodes.size()].w1 ^= value; break;
+                case 2: refs[at % refs.size()] ^= value; break;
+                case 3: mats[at % mats.size()] ^= value; break;
+                default: kinds[at % kinds.size()] ^= (uint8_t)value; break;
+                }
+            }
+            mrt_scene_desc d = flat->desc;
+            d.nodes = nodes.data(), d.refs = refs.data(), d.obj_material = mats.data(), d.obj_kind = kinds.data();
+            mrt_scene* dev = nullptr;
+            mrt_status st  = mrt_scene_create( &d, 0, &dev );
+            if ( st == MRT_OK ) mrt_scene_destroy( dev );
+            else CHECK( st == MRT_ERR_INVALID || st == MRT_ERR_UNSUPPORTED || st == MRT_ERR_DEVICE );
+        }
+    }
     delete tree;
     freeScene( scene );
     return 0;
