@@ -269,6 +269,11 @@ struct Texture {
     V3 even, odd;
     Xf xf;
 };
+inline int texel_index( float f, uint32_t n ) {
+    if ( !( f >= 0.f ) ) return 0;
+    if ( f >= (float)( n - 1 ) ) return (int)n - 1;
+    return (int)f;
+}
 inline V3 texture_value( const Texture& t, float u, float v ) {
     // texture::value(u, v, duv) (textures.hpp:21-43): only the transform, then a point lookup
     V3 uvw = t.xf.to( v3( u, v, 0 ) );
@@ -281,8 +286,13 @@ inline V3 texture_value( const Texture& t, float u, float v ) {
         if ( ux <= 0.5 ) return ( vy <= 0.5 ) ? t.even : t.odd;
         return ( vy <= 0.5 ) ? t.odd : t.even;
     }
-    int u2 = ux * ( t.w - 1 ); // textures.hpp:110-119
-    int v2 = vy * ( t.h - 1 );
+    // textures.hpp:110-119.  ux, vy are in [0, 1] for every finite coordinate below 2^31; a NaN
+    // coordinate (a NaN ray "hits" a plane: every comparison of Plane::intersect is false) or one
+    // beyond the int range makes the reference's float -> int conversions undefined (on x86 it then
+    // reads far outside the image).  texel_index is that conversion with those cases defined, the
+    // same way in the kernels: not >= 0 -> 0, beyond the last texel -> the last texel.
+    int u2 = texel_index( ux * ( t.w - 1 ), t.w );
+    int v2 = texel_index( vy * ( t.h - 1 ), t.h );
     size_t px = (size_t)( t.h - v2 - 1 ) * t.w + u2;
     return v3( t.texels + 3 * px );
 }

@@ -236,6 +236,11 @@ MRT_DEV V3 rotate_point( V4 q, V3 v ) { // Material.cpp:116-120
 }
 
 // ------------------------------------------------------------------ textures.hpp:21-43, 64-125
+MRT_DEV int texel_index( float f, uint32_t n ) {
+    if ( !( f >= 0.f ) ) return 0;
+    if ( f >= (float)( n - 1 ) ) return (int)n - 1;
+    return (int)f;
+}
 MRT_DEV V3 texture_value( const DShade& s, int32_t ti, float u, float v ) {
     const DTexture& t = s.textures[ti];
     V3 uvw = mat_mul( t.xf.inv, mk3( u, v, 0.f ) - mk3( t.xf.t[0], t.xf.t[1], t.xf.t[2] ) );
@@ -248,13 +253,12 @@ MRT_DEV V3 texture_value( const DShade& s, int32_t ti, float u, float v ) {
         bool even = ( ux <= 0.5f ) == ( vy <= 0.5f );
         return even ? ld3( t.even ) : ld3( t.odd );
     }
-    int u2     = (int)( ux * (float)( t.w - 1 ) );
-    int v2     = (int)( vy * (float)( t.h - 1 ) );
-    // ux, vy are in [0, 1] unless a texture coordinate is beyond the int range (or infinite), where
-    // the reference's conversions are undefined; the clamps change no defined result and keep the
-    // read inside the image
-    u2         = min( max( u2, 0 ), (int)t.w - 1 );
-    v2         = min( max( v2, 0 ), (int)t.h - 1 );
+    // ux, vy are in [0, 1] for every finite coordinate below 2^31.  A NaN coordinate (a NaN ray
+    // "hits" a plane: every comparison of Plane::intersect is false) or one beyond the int range
+    // makes the reference's float -> int conversions undefined; texel_index defines them (not >= 0
+    // -> 0, beyond the last texel -> the last texel) and is the plain conversion otherwise.
+    int u2     = texel_index( ux * (float)( t.w - 1 ), t.w );
+    int v2     = texel_index( vy * (float)( t.h - 1 ), t.h );
     uint64_t p = (uint64_t)( t.h - v2 - 1 ) * t.w + u2;
     return ld3( s.texels + t.offset + 3 * p );
 }

@@ -107,10 +107,12 @@ def rays_hard(flat, seed, n=12000):
     return np.ascontiguousarray(o), np.ascontiguousarray(d), tmin, tmax
 
 
-def make_shaded(seed, min_roughness=0.0):
+def make_shaded(seed, min_roughness=0.0, rich=False):
     """A random scene for the shading loop: meshes of random Cook-Torrance materials (all three types,
     roughness down to 0, checker textures), spheres, a floor plane, and lights drawn from: a synthetic
-    environment map, sphere lights, triangle lights; thin-lens camera."""
+    environment map, sphere lights, triangle lights; thin-lens camera.  rich: also image textures under
+    rotated and scaled texture transforms, random texture coordinates and smooth (unnormalised) vertex
+    normals, and a third of the triangles under rotated, non-uniformly scaled object transforms."""
     from raytracer_amd import abi, scenes
     rng = np.random.default_rng(seed + 9000)
     sc = Scene()
@@ -121,8 +123,19 @@ def make_shaded(seed, min_roughness=0.0):
         m = sc.CreateMaterial(typ, albedo=tuple(float(x) for x in rng.random(3)), roughness=rough, metalness=float(rng.choice([0.0, 0.1, 1.0])),
                               ior=float(1.0 + rng.random()))
         if typ != abi.MRT_MAT_TRANSPARENT and rng.random() < 0.3:
-            sc.set_checker(m, tuple(float(x) for x in rng.random(3)), tuple(float(x) for x in rng.random(3)), Transform().scale(0.25, 0.25, 1))
+            if rich and rng.random() < 0.5:
+                tw, th = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+                txf = Transform().scale(float(0.2 + rng.random()), float(0.2 + rng.random()), 1).rotate((0, 0, 1), float(rng.random() * 360)).translate(
+                    (float(rng.random()), float(rng.random()), 0))
+                sc.set_image_texture(m, (rng.integers(0, 256, (th, tw, 3)) / 255.0).astype(np.float32), txf)
+            else:
+                sc.set_checker(m, tuple(float(x) for x in rng.random(3)), tuple(float(x) for x in rng.random(3)), Transform().scale(0.25, 0.25, 1))
         mats.append(m)
+    xfs = [Transform()]
+    if rich:
+        for i in range(4):
+            xfs.append(Transform().scale(*(float(x) for x in 0.5 + rng.random(3))).rotate(tuple(float(x) for x in rng.random(3) + 0.1), float(rng.random() * 360)).translate(
+                tuple(float(x) for x in rng.random(3) - 0.5)))
     nrm = np.tile(np.array([0, 0, 1], np.float32), 3)
     uv = np.array([0, 0, 1, 0, 0, 1], np.float32)
     for i in range(int(rng.integers(30, 200))):
@@ -132,7 +145,13 @@ def make_shaded(seed, min_roughness=0.0):
         fn = np.cross(e1, e2)
         fn = fn / max(np.linalg.norm(fn), 1e-20)
         n3 = np.tile(fn.astype(np.float32), 3) if rng.random() < 0.7 else nrm
-        sc.add_triangle(p, n3, tuple(float(x) for x in fn), uv, Transform(), mats[int(rng.integers(0, len(mats)))])
+        tuv, xf = uv, xfs[0]
+        if rich:
+            if rng.random() < 0.4:
+                n3 = (n3 + (rng.random(9) - 0.5).astype(np.float32) * np.float32(0.8)).astype(np.float32)
+            tuv = (rng.random(6) * 3 - 1).astype(np.float32)
+            xf = xfs[int(rng.integers(0, len(xfs)))] if rng.random() < 0.35 else xfs[0]
+        sc.add_triangle(p, n3, tuple(float(x) for x in fn), tuv, xf, mats[int(rng.integers(0, len(mats)))])
     for i in range(int(rng.integers(1, 6))):
         t = Transform().scale(*(0.3 + 0.5 * rng.random(3))).translate(tuple(float(x) for x in (rng.random(3) * 3 - 1.5)))
         sc.add_sphere(t, mats[int(rng.integers(0, len(mats)))])

@@ -1,5 +1,5 @@
 """mrt_render against the oracle's path tracer (same counter-based samples) on the random shaded
-scenes of tests/fuzz_scenes.py.  usage: fuzz_render.py first_seed n_seeds [min_roughness]"""
+scenes of tests/fuzz_scenes.py.  usage: fuzz_render.py first_seed n_seeds [min_roughness [rich]]"""
 import sys
 sys.path.insert(0, '/root/repo')
 import numpy as np
@@ -7,10 +7,11 @@ from raytracer_amd.host import DeviceScene, render_params
 from tests import orc, fuzz_scenes
 first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 1)
 min_roughness = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+rich = len(sys.argv) > 4 and sys.argv[4] == "rich"
 W, H, SX, SY = 64, 48, 2, 2
 worst = 0.0
 for seed in range(first, first + count):
-    sc = fuzz_scenes.make_shaded(seed, min_roughness)
+    sc = fuzz_scenes.make_shaded(seed, min_roughness, rich)
     flat = sc.initKdTree(2).flatten(1)
     dev = DeviceScene(flat)
     p = render_params(W, H, SX, SY, max_depth=6, seed=seed + 1)
