@@ -2,6 +2,8 @@
 #include "host_math.hpp"
 
 #include <algorithm>
+#include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -316,8 +318,9 @@ IBL::IBL( const std::string& filename ) {
 namespace {
 
 struct MtlRec {
-    float Kd[3] = { 0.6f, 0.6f, 0.6f }, Ke[3] = { 0, 0, 0 }, Ks[3] = { 0, 0, 0 };
+    float Kd[3] = { 0.f, 0.f, 0.f }, Ke[3] = { 0, 0, 0 }, Ks[3] = { 0, 0, 0 }; // InitMaterial (tiny_obj_loader.h:853-888)
     float Ni    = 1.f;
+    std::string name;
 };
 
 struct ObjData {
@@ -330,49 +333,202 @@ struct ObjData {
     std::vector<MtlRec> mtls;
 };
 
-bool parse_mtl( const std::string& path, std::vector<MtlRec>& out, std::map<std::string, int>& names ) {
-    std::ifstream f( path );
-    if ( !f ) return false;
-    std::string line;
-    MtlRec* cur = nullptr;
-    while ( std::getline( f, line ) ) {
-        std::istringstream ss( line );
-        std::string tag;
-        if ( !( ss >> tag ) ) continue;
-        if ( tag == "newmtl" ) {
-            std::string name;
-            ss >> name;
-            names[name] = (int)out.size();
-            out.emplace_back();
-            cur = &out.back();
-        }
-        else if ( cur ) {
-            auto rd3 = [&]( float* d ) {
-                double a = 0, b = 0, c = 0;
-                ss >> a >> b >> c;
-                d[0] = (float)a;
-                d[1] = (float)b;
-                d[2] = (float)c;
-            };
-            if ( tag == "Kd" ) rd3( cur->Kd );
-            else if ( tag == "Ke" ) rd3( cur->Ke );
-            else if ( tag == "Ks" ) rd3( cur->Ks );
-            else if ( tag == "Ni" ) {
-                double a = 1;
-                ss >> a;
-                cur->Ni = (float)a;
-            }
+// What follows restates the OBJ / MTL reading of the reference's tiny_obj_loader.h (v1.0.6) statement
+// by statement: which faces exist, their order (it numbers the primitives) and every float depend on
+// its grammar and on its arithmetic, neither of which is strtod's.
+
+inline bool is_space( char c ) {
+    return c == ' ' || c == '\t';
+}
+inline bool is_digit( char c ) {
+    return (unsigned)( c - '0' ) < 10u;
+}
+inline bool is_new_line( char c ) {
+    return c == '\r' || c == '\n' || c == '\0';
+}
+
+// safeGetline (tiny_obj_loader.h:389-417): a line ends at \n, \r\n or a lone \r.
+std::istream& get_line( std::istream& is, std::string& t ) {
+    t.clear();
+    std::istream::sentry se( is, true );
+    std::streambuf* sb = is.rdbuf();
+    for ( ;; ) {
+        int c = sb->sbumpc();
+        switch ( c ) {
+        case '\n': return is;
+        case '\r':
+            if ( sb->sgetc() == '\n' ) sb->sbumpc();
+            return is;
+        case EOF:
+            if ( t.empty() ) is.setstate( std::ios::eofbit );
+            return is;
+        default: t += (char)c;
         }
     }
+}
+
+// tryParseDouble (tiny_obj_loader.h:474-587).  Grammar: [sign] digits ["." digits] [("e"|"E") [sign]
+// digits]; a number has to start with a sign or a digit and have a digit before any "." (".5", "-.5"
+// and "-" fail; "5." is 5).  A word that fails reads as the default, 0.  Arithmetic: the integer digits accumulate as m = m * 10 + d, the
+// k-th decimal adds d * 10^-k (a table of literals for k < 8, pow(10, -k) beyond), an exponent e
+// applies as ldexp(m * pow(5, e), e): a few units in the last place of the double away from the
+// correctly rounded value, which shows in the float now and then.
+bool parse_double( const char* s, const char* s_end, double* result ) {
+    if ( s >= s_end ) return false;
+    double mantissa = 0.0;
+    int exponent    = 0;
+    char sign = '+', exp_sign = '+';
+    const char* curr = s;
+    int read         = 0;
+    bool more        = false; // curr has not reached s_end
+    if ( *curr == '+' || *curr == '-' ) {
+        sign = *curr;
+        curr++;
+    }
+    else if ( !is_digit( *curr ) ) return false;
+    more = curr != s_end;
+    while ( more && is_digit( *curr ) ) {
+        mantissa *= 10;
+        mantissa += (int)( *curr - '0' );
+        curr++, read++;
+        more = curr != s_end;
+    }
+    if ( read == 0 ) return false;
+    bool assemble = !more;
+    if ( !assemble ) {
+        if ( *curr == '.' ) {
+            curr++;
+            read = 1;
+            more = curr != s_end;
+            while ( more && is_digit( *curr ) ) {
+                static const double pow_lut[] = { 1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001 };
+                const int lut_entries         = 8;
+                mantissa += (int)( *curr - '0' ) * ( read < lut_entries ? pow_lut[read] : std::pow( 10.0, -read ) );
+                read++, curr++;
+                more = curr != s_end;
+            }
+        }
+        else if ( *curr != 'e' && *curr != 'E' ) { assemble = true; }
+        if ( !assemble && more && ( *curr == 'e' || *curr == 'E' ) ) {
+            curr++;
+            more = curr != s_end;
+            // at s_end the reference looks at the character there (a blank, a \r or the string's end): no digit
+            if ( more && ( *curr == '+' || *curr == '-' ) ) {
+                exp_sign = *curr;
+                curr++;
+            }
+            else if ( !( more && is_digit( *curr ) ) ) return false;
+            read = 0;
+            more = curr != s_end;
+            while ( more && is_digit( *curr ) ) {
+                exponent *= 10;
+                exponent += (int)( *curr - '0' );
+                curr++, read++;
+                more = curr != s_end;
+            }
+            exponent *= ( exp_sign == '+' ? 1 : -1 );
+            if ( read == 0 ) return false;
+        }
+    }
+    *result = ( sign == '+' ? 1 : -1 ) * ( exponent ? std::ldexp( mantissa * std::pow( 5.0, exponent ), exponent ) : mantissa );
     return true;
 }
 
-int fix_index( int idx, size_t n ) { // OBJ: 1-based, negative = relative to the end
-    if ( idx > 0 ) return idx - 1;
-    if ( idx < 0 ) return (int)n + idx;
-    return -1;
+// parseReal (tiny_obj_loader.h:589-597): the next blank-delimited word, default_value when it is no number
+float parse_real( const char** token, double default_value = 0.0 ) {
+    ( *token ) += std::strspn( *token, " \t" );
+    const char* end = ( *token ) + std::strcspn( *token, " \t\r" );
+    double val      = default_value;
+    parse_double( *token, end, &val );
+    *token = end;
+    return (float)val;
 }
 
+// sscanf( token, "%s", namebuf ): the first word after any white space (empty when there is none)
+std::string scan_word( const char* token ) {
+    while ( *token && std::isspace( (unsigned char)*token ) )
+        token++;
+    const char* e = token;
+    while ( *e && !std::isspace( (unsigned char)*e ) )
+        e++;
+    return std::string( token, e );
+}
+
+// LoadMtl (tiny_obj_loader.h:965-1333) for the four statements the scene builder reads.  A material
+// is stored when the next newmtl arrives (if it has a name) and the last one always, named or not;
+// of two materials of one name the first is the one usemtl finds.
+void parse_mtl( std::istream& f, std::vector<MtlRec>& out, std::map<std::string, int>& names ) {
+    MtlRec material;
+    std::string line;
+    while ( f.peek() != -1 ) {
+        get_line( f, line );
+        if ( !line.empty() ) line = line.substr( 0, line.find_last_not_of( " \t" ) + 1 );
+        if ( !line.empty() && line.back() == '\n' ) line.pop_back();
+        if ( !line.empty() && line.back() == '\r' ) line.pop_back();
+        if ( line.empty() ) continue;
+        const char* token = line.c_str();
+        token += std::strspn( token, " \t" );
+        if ( token[0] == '\0' || token[0] == '#' ) continue;
+        if ( std::strncmp( token, "newmtl", 6 ) == 0 && is_space( token[6] ) ) {
+            if ( !material.name.empty() ) {
+                names.insert( { material.name, (int)out.size() } );
+                out.push_back( material );
+            }
+            material      = MtlRec();
+            material.name = scan_word( token + 7 );
+            continue;
+        }
+        auto rd3 = [&]( float* d ) {
+            token += 2;
+            d[0] = parse_real( &token );
+            d[1] = parse_real( &token );
+            d[2] = parse_real( &token );
+        };
+        if ( token[0] == 'K' && token[1] == 'd' && is_space( token[2] ) ) rd3( material.Kd );
+        else if ( token[0] == 'K' && token[1] == 's' && is_space( token[2] ) ) rd3( material.Ks );
+        else if ( token[0] == 'K' && token[1] == 'e' && is_space( token[2] ) ) rd3( material.Ke );
+        else if ( token[0] == 'N' && token[1] == 'i' && is_space( token[2] ) ) {
+            token += 2;
+            material.Ni = parse_real( &token );
+        }
+    }
+    names.insert( { material.name, (int)out.size() } );
+    out.push_back( material );
+}
+
+int fix_index( int idx, int n ) { // fixIndex (tiny_obj_loader.h:425-429): 1-based, negative = relative to the end, 0 stays 0
+    if ( idx > 0 ) return idx - 1;
+    if ( idx == 0 ) return 0;
+    return n + idx;
+}
+
+// parseTriple (tiny_obj_loader.h:691-722): i, i/j, i//k, i/j/k
+ObjData::Corner parse_triple( const char** token, int vsize, int vnsize, int vtsize ) {
+    ObjData::Corner vi { -1, -1, -1 };
+    vi.v = fix_index( std::atoi( *token ), vsize );
+    ( *token ) += std::strcspn( *token, "/ \t\r" );
+    if ( ( *token )[0] != '/' ) return vi;
+    ( *token )++;
+    if ( ( *token )[0] == '/' ) {
+        ( *token )++;
+        vi.vn = fix_index( std::atoi( *token ), vnsize );
+        ( *token ) += std::strcspn( *token, "/ \t\r" );
+        return vi;
+    }
+    vi.vt = fix_index( std::atoi( *token ), vtsize );
+    ( *token ) += std::strcspn( *token, "/ \t\r" );
+    if ( ( *token )[0] != '/' ) return vi;
+    ( *token )++;
+    vi.vn = fix_index( std::atoi( *token ), vnsize );
+    ( *token ) += std::strcspn( *token, "/ \t\r" );
+    return vi;
+}
+
+// LoadObj (tiny_obj_loader.h:1424-1730) with triangulation.  Faces collect in a group; usemtl with
+// another material moves the group into the current shape, g / o close the shape.  One behaviour of
+// that version is kept because it decides which primitives exist: when g or o follows a usemtl
+// with no face in between, the faces the shape already holds are dropped with it (the shape is
+// only kept when the group that closes it is not empty); at the end of the file they are kept.
 void parse_obj( const char* filename, ObjData& d ) {
     std::ifstream f( filename );
     if ( !f ) throw std::runtime_error( std::string( "cannot open OBJ file " ) + filename );
@@ -380,81 +536,92 @@ void parse_obj( const char* filename, ObjData& d ) {
     size_t slash    = dir.find_last_of( "/\\" );
     dir             = ( slash == std::string::npos ) ? std::string( "" ) : dir.substr( 0, slash + 1 );
     std::map<std::string, int> mtl_names;
-    int cur_mtl = -1;
+    int material = -1;
+    std::vector<std::vector<ObjData::Corner>> group; // faceGroup
+    std::vector<ObjData::Corner> shape_corners;       // shape.mesh.indices
+    std::vector<int> shape_mtl;                       // shape.mesh.material_ids
+    auto export_group = [&]() {                       // exportFaceGroupToShape (tiny_obj_loader.h:890-951)
+        if ( group.empty() ) return false;
+        for ( const auto& face : group )
+            for ( size_t k = 2; k < face.size(); k++ ) {
+                shape_corners.push_back( face[0] );
+                shape_corners.push_back( face[k - 1] );
+                shape_corners.push_back( face[k] );
+                shape_mtl.push_back( material );
+            }
+        return true;
+    };
+    auto close_shape = [&]( bool keep ) {
+        if ( keep ) {
+            d.corners.insert( d.corners.end(), shape_corners.begin(), shape_corners.end() );
+            d.face_mtl.insert( d.face_mtl.end(), shape_mtl.begin(), shape_mtl.end() );
+        }
+        shape_corners.clear();
+        shape_mtl.clear();
+        group.clear();
+    };
     std::string line;
-    while ( std::getline( f, line ) ) {
-        const char* s = line.c_str();
-        while ( *s == ' ' || *s == '\t' )
-            s++;
-        if ( s[0] == 'v' && ( s[1] == ' ' || s[1] == '\t' ) ) {
-            char* e;
-            for ( int k = 0; k < 3; k++ ) {
-                d.v.push_back( (float)std::strtod( s + ( k == 0 ? 1 : 0 ), &e ) );
-                s = e;
+    while ( f.peek() != -1 ) {
+        get_line( f, line );
+        if ( !line.empty() && line.back() == '\n' ) line.pop_back();
+        if ( !line.empty() && line.back() == '\r' ) line.pop_back();
+        if ( line.empty() ) continue;
+        const char* token = line.c_str();
+        token += std::strspn( token, " \t" );
+        if ( token[0] == '\0' || token[0] == '#' ) continue;
+        if ( token[0] == 'v' && is_space( token[1] ) ) {
+            token += 2;
+            for ( int k = 0; k < 3; k++ )
+                d.v.push_back( parse_real( &token ) );
+        }
+        else if ( token[0] == 'v' && token[1] == 'n' && is_space( token[2] ) ) {
+            token += 3;
+            for ( int k = 0; k < 3; k++ )
+                d.vn.push_back( parse_real( &token ) );
+        }
+        else if ( token[0] == 'v' && token[1] == 't' && is_space( token[2] ) ) {
+            token += 3;
+            for ( int k = 0; k < 2; k++ )
+                d.vt.push_back( parse_real( &token ) );
+        }
+        else if ( token[0] == 'f' && is_space( token[1] ) ) {
+            token += 2;
+            token += std::strspn( token, " \t" );
+            std::vector<ObjData::Corner> face;
+            while ( !is_new_line( token[0] ) ) {
+                face.push_back( parse_triple( &token, (int)( d.v.size() / 3 ), (int)( d.vn.size() / 3 ), (int)( d.vt.size() / 2 ) ) );
+                token += std::strspn( token, " \t\r" );
+            }
+            group.push_back( std::move( face ) );
+        }
+        else if ( std::strncmp( token, "usemtl", 6 ) == 0 && is_space( token[6] ) ) {
+            auto it            = mtl_names.find( scan_word( token + 7 ) );
+            const int new_mtl  = ( it == mtl_names.end() ) ? -1 : it->second;
+            if ( new_mtl != material ) {
+                export_group();
+                group.clear();
+                material = new_mtl;
             }
         }
-        else if ( s[0] == 'v' && s[1] == 'n' ) {
-            char* e;
-            s += 2;
-            for ( int k = 0; k < 3; k++ ) {
-                d.vn.push_back( (float)std::strtod( s, &e ) );
-                s = e;
-            }
-        }
-        else if ( s[0] == 'v' && s[1] == 't' ) {
-            char* e;
-            s += 2;
-            for ( int k = 0; k < 2; k++ ) {
-                d.vt.push_back( (float)std::strtod( s, &e ) );
-                s = e;
-            }
-        }
-        else if ( s[0] == 'f' && ( s[1] == ' ' || s[1] == '\t' ) ) {
-            s += 1;
-            std::vector<ObjData::Corner> poly;
-            while ( *s ) {
-                while ( *s == ' ' || *s == '\t' || *s == '\r' )
-                    s++;
-                if ( !*s ) break;
-                char* e;
-                ObjData::Corner c { -1, -1, -1 };
-                c.v = fix_index( (int)std::strtol( s, &e, 10 ), d.v.size() / 3 );
-                s   = e;
-                if ( *s == '/' ) {
-                    s++;
-                    if ( *s != '/' ) {
-                        c.vt = fix_index( (int)std::strtol( s, &e, 10 ), d.vt.size() / 2 );
-                        s    = e;
-                    }
-                    if ( *s == '/' ) {
-                        s++;
-                        c.vn = fix_index( (int)std::strtol( s, &e, 10 ), d.vn.size() / 3 );
-                        s    = e;
-                    }
-                }
-                poly.push_back( c );
-            }
-            for ( size_t k = 2; k < poly.size(); k++ ) {
-                d.corners.push_back( poly[0] );
-                d.corners.push_back( poly[k - 1] );
-                d.corners.push_back( poly[k] );
-                d.face_mtl.push_back( cur_mtl );
-            }
-        }
-        else if ( std::strncmp( s, "mtllib", 6 ) == 0 ) {
-            std::istringstream ss( s + 6 );
+        else if ( std::strncmp( token, "mtllib", 6 ) == 0 && is_space( token[6] ) ) {
+            // the names are split at single blanks and tried in turn until one file opens (an empty
+            // name, as two blanks in a row make one, opens the directory and yields one unnamed
+            // default material, exactly as the stream the reference opens on it does)
+            std::stringstream ss( std::string( token + 7 ) );
             std::string name;
-            ss >> name;
-            parse_mtl( dir + name, d.mtls, mtl_names );
+            while ( std::getline( ss, name, ' ' ) ) {
+                std::ifstream mf( ( dir + name ).c_str() );
+                if ( !mf ) continue;
+                parse_mtl( mf, d.mtls, mtl_names );
+                break;
+            }
         }
-        else if ( std::strncmp( s, "usemtl", 6 ) == 0 ) {
-            std::istringstream ss( s + 6 );
-            std::string name;
-            ss >> name;
-            auto it = mtl_names.find( name );
-            cur_mtl = ( it == mtl_names.end() ) ? -1 : it->second;
+        else if ( ( token[0] == 'g' || token[0] == 'o' ) && is_space( token[1] ) ) {
+            close_shape( export_group() );
         }
     }
+    const bool ret = export_group();
+    close_shape( ret || !shape_corners.empty() );
 }
 
 struct Tri {
@@ -499,6 +666,10 @@ void addObjectsFromFileEx( const char* filename, Scene* scene, size_t default_ma
         t.mtl   = d.face_mtl[f];
         for ( int k = 0; k < 3; k++ ) {
             const ObjData::Corner& c = d.corners[3 * f + k];
+            // the reference reads whatever lies at an index outside the file's tables; refused here
+            if ( c.v < 0 || (size_t)c.v >= d.v.size() / 3 || ( t.has_n && c.vn >= 0 && (size_t)c.vn >= d.vn.size() / 3 ) ||
+                 ( !d.vt.empty() && c.vt >= 0 && (size_t)c.vt >= d.vt.size() / 2 ) )
+                throw std::runtime_error( std::string( "OBJ file with a face index outside its vertex tables: " ) + filename );
             t.p[k] = vec3( d.v[3 * c.v] * prescale, d.v[3 * c.v + 1] * prescale, d.v[3 * c.v + 2] * prescale );
             if ( t.has_n && c.vn >= 0 ) t.n[k] = vec3( d.vn[3 * c.vn], d.vn[3 * c.vn + 1], d.vn[3 * c.vn + 2] );
             if ( !d.vt.empty() && c.vt >= 0 ) t.t[k] = vec2 { d.vt[2 * c.vt], d.vt[2 * c.vt + 1] };

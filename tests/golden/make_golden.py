@@ -243,6 +243,23 @@ def obj_streams():
         json.dump(summary, f, indent=1)
 
 
+def obj_fuzz():
+    """Digests of the tinyobj streams of the first 100 files of tests/fuzz_obj.py, for machines without
+    the reference build."""
+    import tempfile
+    from tests import fuzz_obj
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for seed in range(100):
+            s = ref_obj_streams(fuzz_obj.make_obj(seed, tmp, "f%d" % seed))
+            out[str(seed)] = {"faces": len(s["pos"]), "materials": int(len(s["mtl"])),
+                              "digest": {k: cases.digest(s[k]) for k in ("pos", "vertex_normals", "tex", "material_id")},
+                              "mtl": cases.digest(np.ascontiguousarray(s["mtl"]))}
+    with open(os.path.join(HERE, "obj_fuzz.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("obj_fuzz: %d files" % len(out))
+
+
 if __name__ == "__main__":
     if not orc.have_ref():
         raise SystemExit("oracle/_ref/libmrt_ref.so is missing: run `make -C oracle ref` in the build container")
@@ -252,5 +269,6 @@ if __name__ == "__main__":
     functions()
     shading_l2()
     obj_streams()
+    obj_fuzz()
     if "--large-trees" in sys.argv:
         large_trees()

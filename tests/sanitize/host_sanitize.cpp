@@ -143,6 +143,38 @@ int main( int argc, char** argv ) {
         CHECK( threw );
     }
     {
+        // OBJ reader on files the reference's loader reads out of bounds for: faces of fewer than three
+        // corners, indices outside the tables, a face before any vertex, bytes that are no text.
+        // Either a scene or a std::runtime_error, never a sanitizer report.
+        const char* cases[] = {
+            "v 0 0 0\nv 1 0 0\nv 0 1 0\nf\nf 1\nf 1 2\nf 1 2 3\n",
+            "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 4\n",
+            "f 1 2 3\nv 0 0 0\n",
+            "v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//2 3//-5\n",
+            "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nf 1/9 2/1 3/1\n",
+            "v 0 0 0\nv 1 0 0\nv 0 1 0\nf -1 -2 -7\n",
+            "v 1e999 -1e-999 1e+\nv . - +\nv 1 2\nf 1 2 3\nusemtl\nmtllib\ng\no\n",
+            "\x01\x02\xff\xfe f 1 2 3 \x00 v v v\rf 2147483648 -2147483649 99999999999999999999\r",
+        };
+        const std::string path = "/tmp/mrt_host_sanitize_case.obj";
+        for ( const char* text : cases ) {
+            {
+                std::ofstream out( path, std::ios::binary );
+                out << text;
+            }
+            Scene* s    = initScene();
+            Material& m = s->CreateMaterial( MaterialModel::COOK_TORRANCE );
+            Transform t;
+            try {
+                addObjectsFromFile( path.c_str(), s, m, t );
+            }
+            catch ( const std::runtime_error& ) {
+            }
+            freeScene( s );
+        }
+        std::remove( path.c_str() );
+    }
+    {
         // PNG reader: the texture of scene 18, then the same bytes cut short and damaged (every
         // outcome but a clean decode or a clean refusal is a sanitizer report)
         const std::string png = assets + "/pf-s125-ake7011-a.png";

@@ -465,6 +465,80 @@ def test_benchmark_scene_trees_identical_to_reference(built, name):
     assert bits(np.array(d.root_min)).tolist() == summary["root_min"] and bits(np.array(d.root_max)).tolist() == summary["root_max"]
 
 
+@pytest.mark.ref
+def test_obj_loader_random_files_against_the_references_tinyobj(built, tmp_path):
+    """300 seeded OBJ + MTL files (tests/fuzz_obj.py: number spellings incl. the ones tinyobj's grammar
+    refuses, white space, \\n / \\r\\n / \\r line ends, polygons of 3-7 corners, relative, zero and signed
+    indices, groups and objects, repeated material names, statements before the first newmtl, mtllib
+    lines with several names / a missing file / two blanks, usemtl straight before g or o) through
+    the reference's tiny_obj_loader.h, live, and through addObjectsFromFile: the same faces in the
+    same order, positions / vertex normals / texture coordinates bit for bit, the same per-face
+    materials."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden
+    from tests import fuzz_obj
+    dropped = refused = 0
+    for seed in range(300):
+        path = fuzz_obj.make_obj(seed, str(tmp_path), "f%d" % seed)
+        ref = make_golden.ref_obj_streams(path)
+        text = open(path, newline="").read().replace("\r\n", "\n").replace("\r", "\n")
+        fans = sum(max(len(l.split()) - 3, 0) for l in text.split("\n") if l.strip().startswith("f"))
+        refused += any(w in text for w in (" nan", " abc", " -.75"))
+        sc = Scene()
+        default = sc.CreateMaterial()
+        n = sc.addObjectsFromFile(path, default, Transform())
+        assert n == len(ref["pos"]), seed
+        dropped += n < fans
+        if n == 0:
+            continue
+        sc.setSimpleCamera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 32, 32, 0.0, 5.0)
+        flat = sc.initKdTree(1).flatten(0)
+        d = flat.desc.contents
+        for k, a in (("pos", np.ctypeslib.as_array(d.tri_p, shape=(n, 9))), ("vertex_normals", np.ctypeslib.as_array(d.tri_n, shape=(n, 9))),
+                     ("tex", np.ctypeslib.as_array(d.tri_uv, shape=(n, 6)))):
+            assert np.array_equal(bits(a).reshape(n, -1), bits(ref[k]).reshape(n, -1)), (seed, k)
+        om = np.ctypeslib.as_array(d.obj_material, shape=(n,))
+        if len(ref["mtl"]) == 0:
+            assert (om == default).all(), seed
+            continue
+        assert np.array_equal(om, default + 1 + np.arange(n)), seed
+        for i in range(n):
+            if ref["material_id"][i] < 0:
+                continue  # the reference indexes materials[-1] for such a face: undefined
+            m, r = d.materials[int(om[i])], ref["mtl"][ref["material_id"][i]]
+            got = np.array([m.ior] + list(m.albedo) + list(m.emission), np.float32)
+            want = np.array(r[:7], np.float32)
+            if not want[4:7].any():
+                want[4:7] = 0  # m_emission is only assigned when a component is non-zero (example_scenes.cpp:93-97): -0 stays +0
+            assert np.array_equal(bits(got), bits(want)), (seed, i)
+            assert (m.type == abi.MRT_MAT_SPECULAR) == bool(r[7] == 1 and r[8] == 1 and r[9] == 1), (seed, i)
+    assert dropped >= 5 and refused >= 5  # the corpus does exercise those two behaviours
+
+
+def test_obj_loader_random_files_against_recorded_tinyobj_digests(built, tmp_path):
+    """The first 100 files of tests/fuzz_obj.py against digests of the streams the reference's
+    tiny_obj_loader.h gave for them (tests/golden/obj_fuzz.json, written by make_golden.py): the same
+    check as the live test above for machines without the reference build."""
+    from tests import fuzz_obj
+    gold = json.load(open(os.path.join(GOLD, "obj_fuzz.json")))
+    for seed in range(100):
+        g = gold[str(seed)]
+        sc = Scene()
+        default = sc.CreateMaterial()
+        n = sc.addObjectsFromFile(fuzz_obj.make_obj(seed, str(tmp_path), "f%d" % seed), default, Transform())
+        assert n == g["faces"], seed
+        if n == 0:
+            continue
+        sc.setSimpleCamera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 32, 32, 0.0, 5.0)
+        flat = sc.initKdTree(1).flatten(0)
+        d = flat.desc.contents
+        for k, a in (("pos", np.ctypeslib.as_array(d.tri_p, shape=(n, 9))), ("vertex_normals", np.ctypeslib.as_array(d.tri_n, shape=(n, 9))),
+                     ("tex", np.ctypeslib.as_array(d.tri_uv, shape=(n, 6)))):
+            assert cases.digest(np.ascontiguousarray(a, np.float32)) == g["digest"][k], (seed, k)
+        assert d.n_materials == 1 + (n if g["materials"] else 0), seed
+
+
 def test_host_library_under_address_and_ub_sanitizers(built):
     """The host library's sources and the host side of the HIP library compiled with
     -fsanitize=address,undefined together with tests/sanitize/host_sanitize.cpp (scene set-up,
