@@ -518,6 +518,14 @@ inline float shape_pdf( const Shape& s, const Isect& inter, V3 wi ) {
 }
 
 // ------------------------------------------------------------------ lights (Light.cpp:247-342)
+// The column / row of a direction: the reference converts phi / 2pi * width and theta / pi * height
+// to int (Light.cpp:309-310, 336-337).  theta is NaN when rounding leaves |dir.y| a unit in the last
+// place above 1 (acos), and the conversion of a NaN is undefined (INT_MIN on x86, and the index
+// computed from it overflows); defined here, and the same way in the kernels, as 0 -- the row of the
+// pole such a direction points at.
+inline int env_coord( double x ) {
+    return x == x ? (int)x : 0;
+}
 inline V3 env_texel( const ShadeScene& sc, int i, int j ) {
     const mrt_scene_desc* d = sc.d;
     long index              = 3L * i + 3L * (long)d->env_width * j;
@@ -531,8 +539,8 @@ inline V3 ibl_Le( const ShadeScene& sc, V3 raydir ) { // Light.cpp:331-342
     double theta = std::acos( dir.y );
     double phi   = std::atan2( dir.z, dir.x );
     if ( phi < 0 ) phi += 2 * M_PI_D;
-    int i = phi / ( 2 * M_PI_D ) * sc.d->env_width;
-    int j = theta / M_PI_D * sc.d->env_height;
+    int i = env_coord( phi / ( 2 * M_PI_D ) * sc.d->env_width );
+    int j = env_coord( theta / M_PI_D * sc.d->env_height );
     return env_texel( sc, i, j );
 }
 inline float ibl_pdf_Li( const ShadeScene& sc, V3 wi ) { // Light.cpp:317-329
@@ -578,8 +586,8 @@ inline V3 light_sample_Li( const ShadeScene& sc, uint32_t li, const Isect& inter
     float theta = std::acos( dir.y );
     float phi   = std::atan2( dir.z, dir.x );
     if ( phi < 0 ) phi += 2 * M_PI_D;
-    int i = phi / ( 2 * M_PI_D ) * sc.d->env_width;
-    int j = theta / M_PI_D * sc.d->env_height;
+    int i = env_coord( phi / ( 2 * M_PI_D ) * sc.d->env_width );
+    int j = env_coord( theta / M_PI_D * sc.d->env_height );
     return env_texel( sc, i, j );
 }
 inline float light_pdf_Li( const ShadeScene& sc, uint32_t li, const Isect& it, V3 wi ) {

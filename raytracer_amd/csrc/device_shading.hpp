@@ -444,13 +444,18 @@ MRT_DEV V3 env_texel( const DShade& s, int i, int j ) {
     if ( index < 0 ) index = 0;
     return ld3( s.env_rgb + index );
 }
+// Column / row of a direction.  theta is NaN when rounding leaves |dir.y| a unit in the last place
+// above 1, and the reference's conversion of a NaN to int is undefined: 0 here (the pole's row).
+MRT_DEV int env_coord( double x ) {
+    return x == x ? (int)x : 0;
+}
 MRT_DEV V3 ibl_Le( const DShade& s, V3 raydir ) { // Light.cpp:331-342 (double theta / phi)
     V3 dir       = mat_mul( s.env_inv, raydir );
     double theta = (double)acosf( dir.y );
     double phi   = (double)atan2f( dir.z, dir.x );
     if ( phi < 0 ) phi += 2 * MRT_PI_D;
-    int i = (int)( phi / ( 2 * MRT_PI_D ) * (double)(int)s.env_w );
-    int j = (int)( theta / MRT_PI_D * (double)(int)s.env_h );
+    int i = env_coord( phi / ( 2 * MRT_PI_D ) * (double)(int)s.env_w );
+    int j = env_coord( theta / MRT_PI_D * (double)(int)s.env_h );
     return env_texel( s, i, j );
 }
 MRT_DEV V3 ibl_sample_texel( const DShade& s, V3 raydir ) { // Light.cpp:304-314 (float theta / phi)
@@ -458,8 +463,8 @@ MRT_DEV V3 ibl_sample_texel( const DShade& s, V3 raydir ) { // Light.cpp:304-314
     float theta = acosf( dir.y );
     float phi   = atan2f( dir.z, dir.x );
     if ( phi < 0 ) phi = (float)( (double)phi + 2 * MRT_PI_D );
-    int i = (int)( (double)phi / ( 2 * MRT_PI_D ) * (double)(int)s.env_w );
-    int j = (int)( (double)theta / MRT_PI_D * (double)(int)s.env_h );
+    int i = env_coord( (double)phi / ( 2 * MRT_PI_D ) * (double)(int)s.env_w );
+    int j = env_coord( (double)theta / MRT_PI_D * (double)(int)s.env_h );
     return env_texel( s, i, j );
 }
 MRT_DEV float ibl_pdf_Li( const DShade& s, V3 wi ) { // Light.cpp:317-329, sampling.h:143-150

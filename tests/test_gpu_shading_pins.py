@@ -202,3 +202,83 @@ def test_resolve_average_and_gamma(built):
     assert abi.hip().mrt_resolve(dev._h, 256, img.ctypes.data, 4, res.ctypes.data, abi.MRT_BUF_HOST, None) == abi.MRT_OK
     near(res, np.power(cpu / np.float32(4), np.float32(1.0 / 2.2), dtype=np.float32), 1e-4, 1e-5, frac=0.995)
     dev.close()
+
+
+def test_device_functions_on_edge_values(built):
+    """Zero, -0, 1, denormal, tiny, huge, infinite and NaN arguments (a quarter of every column) through
+    the device functions against the oracle, which equals the reference's bsdf.cpp bit for bit on the
+    same kind of input (checked live in the container).  A value that is NaN on one side must be NaN
+    on the other; arithmetic-only results are bit-exact; results through expf / acosf / atan2f agree
+    to the usual 2e-6 relative.  Texture coordinates that are NaN, infinite or beyond the int range
+    select the same texel on both sides (texel_index)."""
+    import ctypes as C
+    lib = orc.oracle()
+    vp = C.c_void_p
+    lib.orc_texture_value.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, C.c_int64, vp, vp]
+    lib.orc_ibl.argtypes = [C.POINTER(abi.SceneDesc), C.c_int64, vp, vp]
+    P = orc._p
+    rng = np.random.default_rng(99)
+    n = 20000
+    edge = np.array([0, -0.0, 1, -1, 0.5, 1e-8, 1e-20, 1e-38, 1e-45, 0.002, 4e-6, 0.9999999, 1.0000001, 2, 3e9, -3e9, 1e8, 1e30,
+                     np.inf, -np.inf, np.nan], np.float32)
+
+    def draw(lo, hi, k=n):
+        a = rng.uniform(lo, hi, k).astype(np.float32)
+        m = rng.random(k) < 0.25
+        a[m] = edge[rng.integers(0, len(edge), int(m.sum()))]
+        return a
+
+    def same_class(a, b):
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.array_equal(np.isinf(a), np.isinf(b))
+
+    def near_or_equal(a, b, rel):
+        same_class(a, b)
+        f = np.isfinite(b)
+        with np.errstate(all="ignore"):
+            ok = (bits(a) == bits(b)) | (np.abs(a - b) <= rel * np.abs(b) + 1e-37) | ~f
+        assert ok.all(), (a[~ok][:4], b[~ok][:4])
+
+    sc = cases.texture_scene()
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    ndoth, alpha, ldoth, ext, inn, ddotn = draw(-1, 1), draw(0, 1), draw(-1, 1), draw(1, 2), draw(1, 2), draw(-1, 1)
+    rows = np.stack([ndoth, alpha, ldoth, ext, inn, ddotn], axis=1).copy()
+    out = dev.debug_eval(DBG["BSDF_TERMS"], rows, 3)
+    a = np.zeros(n, np.float32)
+    lib.orc_beckmann(n, P(ndoth), P(alpha), P(a))
+    near_or_equal(out[:, 0], a, 4e-6)
+    lib.orc_fresnel(n, P(ldoth), P(ext), P(inn), P(a))
+    nan = np.isnan(a)
+    assert np.array_equal(np.isnan(out[:, 1]), nan) and np.array_equal(bits(out[:, 1])[~nan], bits(a)[~nan])  # sqrt + arithmetic
+    for tex in (0, 1):
+        uv = np.stack([draw(-3, 3), draw(-3, 3)], axis=1).copy()
+        rows = np.zeros((n, 3), np.float32)
+        rows[:, 0], rows[:, 1:3] = tex, uv
+        out = dev.debug_eval(DBG["TEXTURE"], rows, 3)
+        want = np.zeros((n, 3), np.float32)
+        lib.orc_texture_value(flat.desc, tex, n, P(uv), P(want))
+        assert np.array_equal(bits(out), bits(want)), tex
+    dev.close()
+
+    sc = scenes.small_bunny(32, 32, env_pixels=scenes.synthetic_env())
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    # directions: unit vectors, a quarter of them replaced by the poles, a unit in the last place beyond
+    # the poles (acos gives NaN: row 0 on both sides, env_coord), the other axes, vectors with a NaN
+    # component (column and row 0 on both sides) and the zero vector
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d = np.ascontiguousarray((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32))
+    special = np.array([[0, 1, 0], [0, -1, 0], [0, 1.0000001, 0], [0, -1.0000001, 0], [3e-4, 1.0000001, -2e-4], [1, 0, 0], [0, 0, 1], [0, 0, -1],
+                        [np.nan, 0.5, 0.5], [0.5, np.nan, 0.5], [0.5, 0.5, np.nan], [0, 0, 0]], np.float32)
+    m = rng.random(n) < 0.25
+    d[m] = special[rng.integers(0, len(special), int(m.sum()))]
+    g = dev.debug_eval(4, d, 7)  # IBL
+    o = np.zeros((n, 7), np.float32)
+    lib.orc_ibl(flat.desc, n, P(d), P(o))
+    # texel lookups are discrete: identical except where atan2f / acosf rounding crosses a texel edge
+    assert (np.abs(g[:, 0:6] - o[:, 0:6]).max(axis=1) == 0).mean() > 0.995
+    beyond = (np.abs(d[:, 1]) > 1) | np.isnan(d).any(axis=1)
+    assert beyond.sum() > 500 and np.array_equal(bits(g[beyond, 0:6]), bits(o[beyond, 0:6]))
+    same_class(g[:, 6], o[:, 6])
+    dev.close()
