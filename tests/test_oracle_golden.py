@@ -438,3 +438,52 @@ def test_live_reference_random_scenes_with_ties(built, seed):
             assert np.array_equal(a["prim"][h], b["prim"][h])
             assert np.array_equal(bits(a["u"])[h], bits(b["u"])[h]) and np.array_equal(bits(a["v"])[h], bits(b["v"])[h])
             assert np.array_equal(a["outside"][h], b["outside"][h])
+
+
+@pytest.mark.ref
+def test_live_reference_functions_on_edge_values(built):
+    """Container only: the oracle's bsdf.cpp / sampling restatements against the reference's own
+    functions on zero, -0, denormal, tiny, huge, infinite and NaN arguments (a quarter of every column):
+    bit for bit, a NaN where the reference gives a NaN."""
+    o, r = orc.oracle(), orc.ref()
+    rng = np.random.default_rng(77)
+    n = 100000
+    edge = np.array([0, -0.0, 1, -1, 0.5, 1e-8, 1e-20, 1e-38, 1e-45, 0.002, 4e-6, 0.9999999, 1.0000001, 2, 1e8, 1e30, np.inf, -np.inf, np.nan],
+                    np.float32)
+
+    def draw(lo, hi):
+        a = rng.uniform(lo, hi, n).astype(np.float32)
+        m = rng.random(n) < 0.25
+        a[m] = edge[rng.integers(0, len(edge), int(m.sum()))]
+        return a
+
+    def same(x, y):
+        return bool(((bits(x) == bits(y)) | (np.isnan(x) & np.isnan(y))).all())
+
+    a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    ndoth, alpha = draw(-1, 1), draw(0, 1)
+    o.orc_beckmann(n, P(ndoth), P(alpha), P(a)), r.ref_beckmann(n, P(ndoth), P(alpha), P(b))
+    assert same(a, b)
+    l, e, i = draw(-1, 1), draw(1, 2), draw(1, 2)
+    o.orc_fresnel(n, P(l), P(e), P(i), P(a)), r.ref_fresnel(n, P(l), P(e), P(i), P(b))
+    assert same(a, b)
+    x = [draw(-1, 1) for _ in range(4)] + [draw(0, 1)]
+    o.orc_smith(n, *[P(v) for v in x], P(a)), r.ref_smith(n, *[P(v) for v in x], P(b))
+    assert same(a, b)
+    rows = np.stack([draw(-1, 1) for _ in range(12)], axis=1).copy()
+    A, B = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    o.orc_bsdf(n, P(rows), P(A)), r.ref_bsdf(n, P(rows), P(B))
+    assert same(A, B)
+    base, metal, ld = np.stack([draw(0, 1) for _ in range(3)], axis=1).copy(), draw(0, 1), draw(-1, 1)
+    oo, rr = [np.zeros((n, 3), np.float32) for _ in range(3)], [np.zeros((n, 3), np.float32) for _ in range(3)]
+    o.orc_schlick_f(n, P(base), P(metal), P(ld), *[P(v) for v in oo]), r.ref_schlick_f(n, P(base), P(metal), P(ld), *[P(v) for v in rr])
+    assert all(same(p, q) for p, q in zip(oo, rr))
+    u2 = np.stack([draw(0, 1), draw(0, 1)], axis=1).copy()
+    A2, B2 = np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32)
+    o.orc_uniform_sample_triangle(n, P(u2), P(A2)), r.ref_uniform_sample_triangle(n, P(u2), P(B2))
+    assert same(A2, B2)
+    o.orc_concentric_disk(n, P(u2), P(A2)), r.ref_concentric_disk(n, P(u2), P(B2))
+    assert same(A2, B2)
+    f, g = draw(0, 10), draw(0, 10)
+    o.orc_power_heuristic(n, P(f), P(g), P(a)), r.ref_power_heuristic(n, P(f), P(g), P(b))
+    assert same(a, b)
