@@ -122,7 +122,7 @@ Scene* loadSceneFile( const char* filename, int width, int height, const char* a
             float lens = (float)tk.num();
             tk.expect( "focus" );
             float focus;
-            if ( tk.peek() == "distance" ) {
+            if ( tk.more() && tk.peek() == "distance" ) {
                 tk.word();
                 float d = length( at - from ); // glm::distance / glm::length( at - from )
                 focus   = d;

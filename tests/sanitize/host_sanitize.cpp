@@ -226,6 +226,42 @@ int main( int argc, char** argv ) {
         CHECK( threw );
     }
     {
+        // scene data files with damaged text: a scene or an exception, never a sanitizer report
+        for ( int id : { 9, 18, 21 } ) {
+            std::ifstream f( assets + "/scenes/scene" + std::to_string( id ) + ".scene", std::ios::binary );
+            const std::string text( ( std::istreambuf_iterator<char>( f ) ), std::istreambuf_iterator<char>() );
+            CHECK( text.size() > 100 );
+            const std::string path = "/tmp/mrt_host_sanitize_case.scene";
+            uint32_t state         = 99u + (uint32_t)id;
+            auto next              = [&state]() { return state = state * 1664525u + 1013904223u; };
+            for ( int round = 0; round < 25; round++ ) {
+                std::string bad = text;
+                for ( int k = 0; k < 3; k++ ) {
+                    const size_t at = ( next() >> 4 ) % bad.size();
+                    switch ( ( next() >> 9 ) % 5u ) {
+                    case 0: bad[at] = (char)( next() >> 24 ); break;                          // any byte
+                    case 1: bad.erase( at, ( next() >> 8 ) % 40u ); break;                     // a cut
+                    case 2: bad.insert( at, " -1e999 nan 4294967296 " ); break;                // odd numbers
+                    case 3: bad.insert( at, "\nmaterial\nmesh\nlight\ntexture 99999 x\n" ); break; // statements without arguments
+                    default: bad.resize( at ); break;                                          // a truncated file
+                    }
+                    if ( bad.empty() ) bad = "camera";
+                }
+                {
+                    std::ofstream out( path, std::ios::binary );
+                    out << bad;
+                }
+                try {
+                    Scene* scene = loadSceneFile( path.c_str(), 64, 48, assets.c_str() );
+                    if ( scene ) freeScene( scene );
+                }
+                catch ( const std::exception& ) {
+                }
+            }
+            std::remove( path.c_str() );
+        }
+    }
+    {
         // an empty scene: no tree, nothing to flatten but the tables
         Scene* scene = initScene();
         scene->CreateMaterial( MaterialModel::COOK_TORRANCE );
