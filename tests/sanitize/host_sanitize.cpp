@@ -226,6 +226,46 @@ int main( int argc, char** argv ) {
         CHECK( threw );
     }
     {
+        // Radiance HDR and PPM readers on damaged and truncated files: a picture, a null texture or an
+        // exception
+        struct Case {
+            std::string file;
+            bool hdr;
+        };
+        for ( const Case& c : { Case { assets + "/brown_photostudio_06_1k.hdr", true }, Case { assets + "/indoor_plant_2_COL_1k.ppm", false } } ) {
+            std::ifstream f( c.file, std::ios::binary );
+            std::vector<char> bytes( ( std::istreambuf_iterator<char>( f ) ), std::istreambuf_iterator<char>() );
+            CHECK( bytes.size() > 1000 );
+            const std::string path = c.hdr ? "/tmp/mrt_host_sanitize_case.hdr" : "/tmp/mrt_host_sanitize_case.ppm";
+            uint32_t state         = 4242u;
+            auto next              = [&state]() { return state = state * 1664525u + 1013904223u; };
+            for ( int round = 0; round < 30; round++ ) {
+                std::vector<char> bad = bytes;
+                if ( round % 3 == 0 ) bad.resize( ( next() >> 4 ) % bad.size() ); // truncated
+                const size_t span = round % 2 ? std::min<size_t>( bad.size(), 120 ) : bad.size(); // the header, or anywhere
+                for ( int k = 0; k < 6 && span; k++ )
+                    bad[( next() >> 4 ) % span] = (char)( next() >> 24 );
+                {
+                    std::ofstream out( path, std::ios::binary );
+                    out.write( bad.data(), (std::streamsize)bad.size() );
+                }
+                try {
+                    if ( c.hdr ) {
+                        IBL ibl( path );
+                        CHECK( ibl.m_pixels.size() == 3u * (size_t)ibl.m_width * (size_t)ibl.m_height );
+                    }
+                    else {
+                        std::unique_ptr<texture> tex( image_texture( path.c_str() ) );
+                        if ( tex ) CHECK( tex->texels.size() == 3u * (size_t)tex->width * (size_t)tex->height );
+                    }
+                }
+                catch ( const std::exception& ) {
+                }
+            }
+            std::remove( path.c_str() );
+        }
+    }
+    {
         // scene data files with damaged text: a scene or an exception, never a sanitizer report
         for ( int id : { 9, 18, 21 } ) {
             std::ifstream f( assets + "/scenes/scene" + std::to_string( id ) + ".scene", std::ios::binary );
