@@ -10,10 +10,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -64,6 +66,41 @@ struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+// Host staging array whose elements start uninitialised: the tables made at scene creation run to
+// hundreds of megabytes and every element is written exactly once, so value-initialising them first
+// (what std::vector does) would touch all that memory twice.
+template <typename T>
+struct HostBuf {
+    T* p     = nullptr;
+    size_t n = 0;
+    HostBuf() = default;
+    explicit HostBuf( size_t count ) : p( count ? (T*)std::malloc( count * sizeof( T ) ) : nullptr ), n( count ) {
+        if ( count && !p ) throw std::bad_alloc();
+    }
+    HostBuf( const HostBuf& )            = delete;
+    HostBuf& operator=( const HostBuf& ) = delete;
+    HostBuf& operator=( HostBuf&& o ) noexcept {
+        std::swap( p, o.p ), std::swap( n, o.n );
+        return *this;
+    }
+    ~HostBuf() { std::free( p ); }
+    T& operator[]( size_t i ) { return p[i]; }
+    const T& operator[]( size_t i ) const { return p[i]; }
+};
+
+// body( begin, end ) over [0, n) cut into one contiguous range per thread (up to 8; one for small n)
+template <class Body>
+void parallel_ranges( size_t n, const Body& body ) {
+    const size_t n_threads = n < ( 1u << 18 ) ? 1u : std::min<size_t>( 8u, std::max( 1u, std::thread::hardware_concurrency() ) );
+    const size_t per       = ( n + n_threads - 1 ) / n_threads;
+    std::vector<std::thread> workers;
+    for ( size_t t = 1; t < n_threads; t++ )
+        workers.emplace_back( [&body, n, per, t]() { body( std::min( n, t * per ), std::min( n, ( t + 1 ) * per ) ); } );
+    body( 0, std::min( n, per ) );
+    for ( std::thread& w : workers )
+        w.join();
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -113,6 +150,10 @@ namespace {
 // Walks the flattened tree on the host: every index must be in range, children must be stored
 // after their parent (which also rules out cycles), no node may have two parents, and the depth must
 // fit the traversal stack.  level[n] receives the parity of node n's depth (2 = not part of the tree).
+// The top of the tree is walked breadth-first by the caller's thread until some hundreds of subtrees
+// are pending; those are then walked depth-first by up to 8 threads.  A node is claimed by an atomic
+// exchange on its level byte, so a second parent is noticed whichever threads the two parents are
+// walked by (which also keeps a malformed description from making the walk exponential).
 mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out, std::vector<uint8_t>& level ) {
     *depth_out = 0;
     level.clear();
@@ -121,31 +162,85 @@ mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out, std::vec
     if ( d->n_refs && !d->refs ) return fail( MRT_ERR_INVALID, "refs is NULL" );
     level.assign( d->n_nodes, 2 );
     level[0] = 0;
-    std::vector<std::pair<uint32_t, uint32_t>> stack;
-    stack.emplace_back( 0u, 0u );
-    while ( !stack.empty() ) {
-        auto [node, depth] = stack.back();
-        stack.pop_back();
-        if ( depth > *depth_out ) *depth_out = depth;
+    std::mutex err_mu;
+    const char* err_msg = nullptr; // the first problem found (string literals only)
+    std::atomic<bool> stop { false };
+    auto problem = [&]( const char* msg ) {
+        std::lock_guard<std::mutex> lock( err_mu );
+        if ( !err_msg ) err_msg = msg;
+        stop.store( true, std::memory_order_relaxed );
+        return false;
+    };
+    // checks one node; for an inner node claims its two children and returns the left one in *left
+    auto visit = [&]( uint32_t node, uint32_t depth, uint32_t* left_out ) {
+        *left_out           = 0;
         const mrt_kdnode& n = d->nodes[node];
         if ( ( n.w1 & 3u ) == 3u ) {
-            uint64_t off = n.w0, cnt = n.w1 >> 2;
-            if ( off + cnt > d->n_refs ) return fail( MRT_ERR_INVALID, "leaf reference range out of bounds" );
+            const uint64_t off = n.w0, cnt = n.w1 >> 2;
+            if ( off + cnt > d->n_refs ) return problem( "leaf reference range out of bounds" );
             for ( uint64_t i = 0; i < cnt; i++ ) {
-                uint32_t obj = d->refs[off + i];
-                if ( obj >= d->n_objects ) return fail( MRT_ERR_INVALID, "leaf references an object out of range" );
-                if ( d->obj_kind[obj] == MRT_PLANE ) return fail( MRT_ERR_INVALID, "a plane must not be inside the tree" );
+                const uint32_t obj = d->refs[off + i];
+                if ( obj >= d->n_objects ) return problem( "leaf references an object out of range" );
+                if ( d->obj_kind[obj] == MRT_PLANE ) return problem( "a plane must not be inside the tree" );
             }
-            continue;
+            return true;
         }
-        uint32_t left = n.w1 >> 2;
-        if ( left <= node || (uint64_t)left + 1 >= d->n_nodes ) return fail( MRT_ERR_INVALID, "child index out of range or not after its parent" );
-        // every node is entered once (so a malformed description cannot make this walk exponential)
-        if ( level[left] != 2 || level[left + 1] != 2 ) return fail( MRT_ERR_INVALID, "a tree node has two parents" );
-        level[left] = level[left + 1] = (uint8_t)( ( depth + 1 ) & 1u );
-        stack.emplace_back( left, depth + 1 );
-        stack.emplace_back( left + 1, depth + 1 );
+        const uint32_t left = n.w1 >> 2;
+        if ( left <= node || (uint64_t)left + 1 >= d->n_nodes ) return problem( "child index out of range or not after its parent" );
+        const uint8_t mark = (uint8_t)( ( depth + 1 ) & 1u );
+        if ( __atomic_exchange_n( &level[left], mark, __ATOMIC_RELAXED ) != 2 || __atomic_exchange_n( &level[left + 1], mark, __ATOMIC_RELAXED ) != 2 )
+            return problem( "a tree node has two parents" );
+        *left_out = left;
+        return true;
+    };
+    typedef std::pair<uint32_t, uint32_t> Entry; // node, depth
+    std::vector<Entry> frontier;
+    frontier.emplace_back( 0u, 0u );
+    uint32_t depth_top = 0;
+    size_t head = 0;
+    while ( head < frontier.size() && frontier.size() - head < 1024 && !stop.load( std::memory_order_relaxed ) ) {
+        const Entry e = frontier[head++];
+        if ( e.second > depth_top ) depth_top = e.second;
+        uint32_t left;
+        if ( visit( e.first, e.second, &left ) && left ) {
+            frontier.emplace_back( left, e.second + 1 );
+            frontier.emplace_back( left + 1, e.second + 1 );
+        }
     }
+    frontier.erase( frontier.begin(), frontier.begin() + (std::ptrdiff_t)head ); // what is left are the pending subtrees
+    std::atomic<size_t> next_subtree { 0 };
+    std::atomic<uint32_t> depth_max { depth_top };
+    auto walk = [&]() {
+        std::vector<Entry> stack;
+        uint32_t deepest = 0;
+        for ( size_t k; ( k = next_subtree.fetch_add( 1 ) ) < frontier.size() && !stop.load( std::memory_order_relaxed ); ) {
+            stack.push_back( frontier[k] );
+            while ( !stack.empty() && !stop.load( std::memory_order_relaxed ) ) {
+                const Entry e = stack.back();
+                stack.pop_back();
+                if ( e.second > deepest ) deepest = e.second;
+                uint32_t left;
+                if ( visit( e.first, e.second, &left ) && left ) {
+                    stack.emplace_back( left, e.second + 1 );
+                    stack.emplace_back( left + 1, e.second + 1 );
+                }
+            }
+            stack.clear();
+        }
+        uint32_t seen = depth_max.load();
+        while ( deepest > seen && !depth_max.compare_exchange_weak( seen, deepest ) ) {}
+    };
+    if ( !stop.load() && !frontier.empty() ) {
+        const size_t n_threads = d->n_nodes < ( 1u << 18 ) ? 1u : std::min<size_t>( 8u, std::max( 1u, std::thread::hardware_concurrency() ) );
+        std::vector<std::thread> workers;
+        for ( size_t t = 1; t < n_threads; t++ )
+            workers.emplace_back( walk );
+        walk();
+        for ( std::thread& w : workers )
+            w.join();
+    }
+    if ( err_msg ) return fail( MRT_ERR_INVALID, err_msg );
+    *depth_out = depth_max.load();
     if ( *depth_out + 2 > MRT_STACK_MAX ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree deeper than the traversal stack (" + std::to_string( *depth_out ) + ")" );
     return MRT_OK;
 }
@@ -153,10 +248,10 @@ mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out, std::vec
 // The tree as the kernels read it: one 32-byte record (two uint4) per node of even depth, holding
 // the node and its two children (layout in device_trace.hpp); records follow the order of the
 // caller's nodes.  Expects the depth parities validate_tree made of a tree that passed it.
-mrt_status build_tree_records( const mrt_scene_desc* d, const std::vector<uint8_t>& level, std::vector<uint4>& nodes ) {
-    nodes.clear();
+mrt_status build_tree_records( const mrt_scene_desc* d, const std::vector<uint8_t>& level, HostBuf<uint4>& nodes ) {
+    nodes = HostBuf<uint4>();
     if ( d->n_nodes ) {
-        std::vector<uint32_t> record( d->n_nodes, 0 );
+        HostBuf<uint32_t> record( d->n_nodes ); // defined for the nodes of even depth
         uint32_t n_records = 0;
         for ( uint32_t i = 0; i < d->n_nodes; i++ )
             if ( level[i] == 0 ) record[i] = n_records++;
@@ -171,14 +266,15 @@ mrt_status build_tree_records( const mrt_scene_desc* d, const std::vector<uint8_
         };
         // the kernels form a record's byte offset (record << 5) in 32 bits
         if ( n_records >= ( 1u << 27 ) ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree too large (limit: 2^27 nodes of even depth)" );
-        nodes.resize( 2 * (size_t)n_records );
-        auto fill = [&]( uint32_t begin, uint32_t end ) {
-            for ( uint32_t i = begin; i < end; i++ ) {
+        nodes = HostBuf<uint4>( 2 * (size_t)n_records );
+        // every record is written by the one thread whose range holds its node
+        parallel_ranges( d->n_nodes, [&]( size_t begin, size_t end ) {
+            for ( size_t i = begin; i < end; i++ ) {
                 if ( level[i] != 0 ) continue;
                 const uint32_t w0 = d->nodes[i].w0, w1 = d->nodes[i].w1;
                 uint32_t l[3] = { 0, 0, 0 }, r[3] = { 0, 0, 0 };
                 uint32_t h0 = 0, h1 = 3;
-                if ( ( w1 & 3u ) == 3u ) child( i, l ); // a leaf of even depth: no head step
+                if ( ( w1 & 3u ) == 3u ) child( (uint32_t)i, l ); // a leaf of even depth: no head step
                 else {
                     h0 = w0, h1 = w1 & 3u;
                     child( w1 >> 2, l );
@@ -187,16 +283,7 @@ mrt_status build_tree_records( const mrt_scene_desc* d, const std::vector<uint8_
                 nodes[2 * (size_t)record[i]]     = make_uint4( h0, h1, l[0], l[1] );
                 nodes[2 * (size_t)record[i] + 1] = make_uint4( r[0], r[1], l[2], r[2] );
             }
-        };
-        // every record is written by the one thread whose range holds its node
-        const uint32_t n_threads = d->n_nodes < ( 1u << 18 ) ? 1u : std::min( 8u, std::max( 1u, std::thread::hardware_concurrency() ) );
-        const uint32_t per       = ( d->n_nodes + n_threads - 1 ) / n_threads;
-        std::vector<std::thread> workers;
-        for ( uint32_t t = 1; t < n_threads; t++ )
-            workers.emplace_back( fill, std::min( d->n_nodes, t * per ), std::min( d->n_nodes, ( t + 1 ) * per ) );
-        fill( 0, std::min( d->n_nodes, per ) );
-        for ( std::thread& w : workers )
-            w.join();
+        } );
     }
     return MRT_OK;
 }
@@ -277,7 +364,17 @@ int32_t mrt_version( void ) {
     return 1;
 }
 
+static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene** out );
 mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** out ) {
+    try { // the host-side tables are large: running out of memory is a status like any other
+        return scene_create( d, device, out );
+    }
+    catch ( const std::bad_alloc& ) {
+        if ( out ) *out = nullptr;
+        return fail( MRT_ERR_NOMEM, "out of host memory while preparing the scene tables" );
+    }
+}
+static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene** out ) {
     if ( !d || !out ) return fail( MRT_ERR_INVALID, "NULL argument" );
     *out = nullptr;
     if ( d->struct_size != sizeof( mrt_scene_desc ) ) return fail( MRT_ERR_INVALID, "mrt_scene_desc.struct_size mismatch" );
@@ -335,13 +432,30 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         }
         else {
             std::fill( place.begin(), place.end(), 0xffffffffu );
-            for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
-                const uint32_t w1 = d->nodes[i].w1;
-                if ( level[i] == 2 || ( w1 & 3u ) != 3u ) continue; // not part of the tree / not a leaf
-                for ( uint32_t k = 0; k < ( w1 >> 2 ); k++ ) {
-                    const uint32_t o = d->refs[d->nodes[i].w0 + k];
-                    if ( place[o] == 0xffffffffu ) place[o] = next++;
+            // every thread lists, in order, the objects first referenced within its range of nodes;
+            // the lists are then merged in range order, which is the order one walk would have found
+            std::vector<std::vector<uint32_t>> firsts;
+            std::mutex firsts_mu;
+            parallel_ranges( d->n_nodes, [&]( size_t begin, size_t end ) {
+                std::vector<uint32_t> mine;
+                std::vector<bool> seen( n_obj, false );
+                for ( size_t i = begin; i < end; i++ ) {
+                    const uint32_t w1 = d->nodes[i].w1;
+                    if ( level[i] == 2 || ( w1 & 3u ) != 3u ) continue; // not part of the tree / not a leaf
+                    for ( uint32_t k = 0; k < ( w1 >> 2 ); k++ ) {
+                        const uint32_t o = d->refs[d->nodes[i].w0 + k];
+                        if ( !seen[o] ) seen[o] = true, mine.push_back( o );
+                    }
                 }
+                std::lock_guard<std::mutex> lock( firsts_mu );
+                firsts.emplace_back( std::move( mine ) );
+                firsts.back().push_back( (uint32_t)begin ); // the range's first node, to put the lists in order
+            } );
+            std::sort( firsts.begin(), firsts.end(), []( const std::vector<uint32_t>& a, const std::vector<uint32_t>& b ) { return a.back() < b.back(); } );
+            for ( std::vector<uint32_t>& list : firsts ) {
+                list.pop_back();
+                for ( uint32_t o : list )
+                    if ( place[o] == 0xffffffffu ) place[o] = next++;
             }
             for ( uint32_t o = 0; o < n_obj; o++ )
                 if ( place[o] == 0xffffffffu ) place[o] = next++;
@@ -349,28 +463,32 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
         for ( uint32_t o = 0; o < n_obj; o++ )
             object_of[place[o]] = o;
     }
-    std::vector<uint8_t> r_kind( n_obj );
-    std::vector<uint32_t> r_material( n_obj ), r_transform( n_obj ), r_refs( d->n_refs ), r_out( d->n_out_of_tree );
-    std::vector<float> r_p( 9 * (size_t)n_obj ), r_n( 9 * (size_t)n_obj ), r_uv( 6 * (size_t)n_obj ), r_sphere( 4 * (size_t)n_obj );
-    for ( uint32_t o = 0; o < n_obj; o++ ) {
-        const size_t t = place[o];
-        r_kind[t] = d->obj_kind[o], r_material[t] = d->obj_material[o], r_transform[t] = d->obj_transform[o];
-        std::memcpy( &r_p[9 * t], d->tri_p + 9 * (size_t)o, 36 );
-        std::memcpy( &r_n[9 * t], d->tri_n + 9 * (size_t)o, 36 );
-        std::memcpy( &r_uv[6 * t], d->tri_uv + 6 * (size_t)o, 24 );
-        std::memcpy( &r_sphere[4 * t], d->sphere + 4 * (size_t)o, 16 );
-    }
-    for ( uint32_t i = 0; i < d->n_refs; i++ )
-        r_refs[i] = d->refs[i] < n_obj ? place[d->refs[i]] : 0u; // references outside every leaf's list are not validated (nor read)
+    HostBuf<uint8_t> r_kind( n_obj );
+    HostBuf<uint32_t> r_material( n_obj ), r_transform( n_obj ), r_refs( d->n_refs ), r_out( d->n_out_of_tree );
+    HostBuf<float> r_p( 9 * (size_t)n_obj ), r_n( 9 * (size_t)n_obj ), r_uv( 6 * (size_t)n_obj ), r_sphere( 4 * (size_t)n_obj );
+    parallel_ranges( n_obj, [&]( size_t begin, size_t end ) {
+        for ( size_t o = begin; o < end; o++ ) {
+            const size_t t = place[o];
+            r_kind[t] = d->obj_kind[o], r_material[t] = d->obj_material[o], r_transform[t] = d->obj_transform[o];
+            std::memcpy( &r_p[9 * t], d->tri_p + 9 * o, 36 );
+            std::memcpy( &r_n[9 * t], d->tri_n + 9 * o, 36 );
+            std::memcpy( &r_uv[6 * t], d->tri_uv + 6 * o, 24 );
+            std::memcpy( &r_sphere[4 * t], d->sphere + 4 * o, 16 );
+        }
+    } );
+    parallel_ranges( d->n_refs, [&]( size_t begin, size_t end ) {
+        for ( size_t i = begin; i < end; i++ )
+            r_refs[i] = d->refs[i] < n_obj ? place[d->refs[i]] : 0u; // references outside every leaf's list are not validated (nor read)
+    } );
     for ( uint32_t i = 0; i < d->n_out_of_tree; i++ )
         r_out[i] = place[d->out_of_tree[i]];
     mrt_scene_desc reordered = *d;
-    reordered.obj_kind = r_kind.data(), reordered.obj_material = r_material.data(), reordered.obj_transform = r_transform.data();
-    reordered.tri_p = r_p.data(), reordered.tri_n = r_n.data(), reordered.tri_uv = r_uv.data(), reordered.sphere = r_sphere.data();
-    reordered.refs = r_refs.data(), reordered.out_of_tree = r_out.data();
+    reordered.obj_kind = r_kind.p, reordered.obj_material = r_material.p, reordered.obj_transform = r_transform.p;
+    reordered.tri_p = r_p.p, reordered.tri_n = r_n.p, reordered.tri_uv = r_uv.p, reordered.sphere = r_sphere.p;
+    reordered.refs = r_refs.p, reordered.out_of_tree = r_out.p;
     d = &reordered;
 
-    std::vector<uint4> nodes;
+    HostBuf<uint4> nodes;
     vs = build_tree_records( d, level, nodes );
     if ( vs != MRT_OK ) return vs;
     level = std::vector<uint8_t>();
@@ -433,7 +551,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     s->n_cus      = n_cus > 0 ? n_cus : 256;
     s->no_emitters = no_emitters;
     s->mixed_kinds = ( kinds_seen & ( kinds_seen - 1u ) ) != 0u;
-    HIP_TRY( s->nodes.upload( nodes ) );
+    HIP_TRY( s->nodes.upload( nodes.p, nodes.n ) );
     HIP_TRY( s->refs.upload( d->refs, d->n_refs ) );
     HIP_TRY( s->prims.upload( prims ) );
     HIP_TRY( s->xforms.upload( xforms ) );
@@ -455,7 +573,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     t.xforms      = s->xforms.p;
     t.out_of_tree = s->out_of_tree.p;
     t.n_nodes     = d->n_nodes;
-    t.n_records   = (uint32_t)( nodes.size() / 2 );
+    t.n_records   = (uint32_t)( nodes.n / 2 );
     t.n_out       = d->n_out_of_tree;
     t.n_xforms    = d->n_transforms;
     {
@@ -464,7 +582,7 @@ mrt_status mrt_scene_create( const mrt_scene_desc* d, int device, mrt_scene** ou
     }
     for ( int k = 0; k < 8; k++ )
         t.root[k] = 0;
-    if ( !nodes.empty() ) {
+    if ( nodes.n ) {
         const uint32_t r[8] = { nodes[0].x, nodes[0].y, nodes[0].z, nodes[0].w, nodes[1].x, nodes[1].y, nodes[1].z, nodes[1].w };
         std::memcpy( t.root, r, sizeof( r ) );
     }
