@@ -71,6 +71,22 @@ def profile_traffic(workload, kernel):
         return None, None
 
 
+def profile_gather_ceiling(workload, kernel):
+    """The kernel's L2 request rate against what a loop of nothing but dependent 32-byte gathers
+    reaches on this GPU at the kernel's occupancy and L2 hit rate (profiles/r02_gather_ceiling.json:
+    tools/micro/gather_bench.hip + the committed counter passes); None when not profiled."""
+    if workload != "million_bunny":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_gather_ceiling.json")) as f:
+            g = json.load(f)
+        k = g["kernels"][kernel]
+        return {"l2_requests_G_per_s": k["g_requests_per_s"], "l2_hit_rate": k["l2_hit_rate"], "ceiling_G_per_s": k["ceiling_g_per_s"],
+                "frac": k["fraction"], "model": g["model"]}
+    except Exception:
+        return None
+
+
 def measure(name, args, rank, world, dist, local_rank, with_cpu):
     """Builds workload `name`, renders warm-up + timed steps (weak split when world > 1) and returns
     the result fields (rank 0) or None (other ranks)."""
@@ -264,6 +280,9 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
         if traffic and launches:
             roof["hbm_frac_from_counters"] = traffic / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof["limiter"] = "L2 / memory-side-cache gather latency (TCC hit rate %.2f)" % hit_rate if hit_rate else "L2 gather latency"
+        gc = profile_gather_ceiling(name, kname) if (spp_x, spp_y) == wl["spp"] and world == 1 else None
+        if gc:
+            roof["gather_ceiling"] = gc
     out["roofline"] = roof
     out["cpu_baseline"] = cpu
     dev.close()

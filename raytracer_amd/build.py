@@ -127,12 +127,24 @@ def build_sanitize(force=False):
     return SANITIZE_BIN
 
 
+GATHER_BENCH = os.path.join(PKG, "gather_bench")
+
+
+def build_tools(force=False):
+    """tools/micro/gather_bench.hip: the random-gather ceilings the traversal kernels are priced against."""
+    src = os.path.join(ROOT, "tools", "micro", "gather_bench.hip")
+    if force or _newer(GATHER_BENCH, [src]):
+        _run(["hipcc", "--offload-arch=gfx950", "-O3", "-o", GATHER_BENCH, src])
+    return GATHER_BENCH
+
+
 def build_all(force=False):
     build_hip(force)
     build_host(force)
     build_example(force)
     build_oracle(force)
     build_ref(force)
+    build_tools(force)
 
 
 if __name__ == "__main__":
