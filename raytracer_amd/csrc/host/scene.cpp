@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -347,24 +348,27 @@ inline bool is_new_line( char c ) {
     return c == '\r' || c == '\n' || c == '\0';
 }
 
-// safeGetline (tiny_obj_loader.h:389-417): a line ends at \n, \r\n or a lone \r.
-std::istream& get_line( std::istream& is, std::string& t ) {
-    t.clear();
-    std::istream::sentry se( is, true );
-    std::streambuf* sb = is.rdbuf();
-    for ( ;; ) {
-        int c = sb->sbumpc();
-        switch ( c ) {
-        case '\n': return is;
-        case '\r':
-            if ( sb->sgetc() == '\n' ) sb->sbumpc();
-            return is;
-        case EOF:
-            if ( t.empty() ) is.setstate( std::ios::eofbit );
-            return is;
-        default: t += (char)c;
-        }
+// The lines of a file as tinyobj's reader cuts them (safeGetline, tiny_obj_loader.h:389-417): a line
+// ends at \n, \r\n or a lone \r; a last line without an end still counts.  A stream that opens but
+// cannot be read (a directory) has no lines.
+std::vector<std::string> read_lines( std::istream& is ) {
+    std::string data;
+    try {
+        data.assign( ( std::istreambuf_iterator<char>( is ) ), std::istreambuf_iterator<char>() );
     }
+    catch ( const std::exception& ) { // what the stream buffer of a directory throws; the reference's peek() turns it into "no more lines"
+        data.clear();
+    }
+    std::vector<std::string> lines;
+    size_t from = 0;
+    for ( size_t i = 0; i < data.size(); i++ ) {
+        if ( data[i] != '\n' && data[i] != '\r' ) continue;
+        lines.emplace_back( data, from, i - from );
+        if ( data[i] == '\r' && i + 1 < data.size() && data[i + 1] == '\n' ) i++;
+        from = i + 1;
+    }
+    if ( from < data.size() ) lines.emplace_back( data, from, data.size() - from );
+    return lines;
 }
 
 // tryParseDouble (tiny_obj_loader.h:474-587).  Grammar: [sign] digits ["." digits] [("e"|"E") [sign]
@@ -459,12 +463,8 @@ std::string scan_word( const char* token ) {
 // of two materials of one name the first is the one usemtl finds.
 void parse_mtl( std::istream& f, std::vector<MtlRec>& out, std::map<std::string, int>& names ) {
     MtlRec material;
-    std::string line;
-    while ( f.peek() != -1 ) {
-        get_line( f, line );
-        if ( !line.empty() ) line = line.substr( 0, line.find_last_not_of( " \t" ) + 1 );
-        if ( !line.empty() && line.back() == '\n' ) line.pop_back();
-        if ( !line.empty() && line.back() == '\r' ) line.pop_back();
+    for ( std::string& line : read_lines( f ) ) {
+        if ( !line.empty() ) line = line.substr( 0, line.find_last_not_of( " \t" ) + 1 ); // trailing blanks are cut (MTL only)
         if ( line.empty() ) continue;
         const char* token = line.c_str();
         token += std::strspn( token, " \t" );
@@ -560,11 +560,7 @@ void parse_obj( const char* filename, ObjData& d ) {
         shape_mtl.clear();
         group.clear();
     };
-    std::string line;
-    while ( f.peek() != -1 ) {
-        get_line( f, line );
-        if ( !line.empty() && line.back() == '\n' ) line.pop_back();
-        if ( !line.empty() && line.back() == '\r' ) line.pop_back();
+    for ( const std::string& line : read_lines( f ) ) {
         if ( line.empty() ) continue;
         const char* token = line.c_str();
         token += std::strspn( token, " \t" );
