@@ -644,3 +644,46 @@ def test_render_rejects_bad_parameters():
     assert lib.mrt_render(dev2._h, C.byref(p), img.ctypes.data_as(C.c_void_p), abi.MRT_BUF_HOST, None, None) == 1
     assert "camera" in lib.mrt_last_error().decode()
     dev2.close()
+
+
+def test_random_frame_shapes_depths_and_splits():
+    """Seeded random combinations of frame size (1 pixel wide to 100, heights that are no multiple of
+    the 8x8 tiles), sample grid, depth 0..6, pass size (down to one path per pass), row tiles and
+    sample chunks on the random shaded scenes: the image equals the oracle's (same non-finite pixels,
+    relMSE <= 1e-5), row tiles add up to it bit for bit, small passes and sample chunks to fp32
+    addition order."""
+    from tests import fuzz_scenes
+    rng = np.random.default_rng(0)
+    for trial in range(16):
+        seed = int(rng.integers(0, 40))
+        sc = fuzz_scenes.make_shaded(seed, 0.05, True)
+        W, H = int(rng.choice([1, 3, 7, 8, 9, 31, 61, 64, 100])), int(rng.choice([1, 2, 5, 8, 17, 37, 48, 75]))
+        sx, sy, depth = int(rng.integers(1, 5)), int(rng.integers(1, 4)), int(rng.integers(0, 7))
+        sc.setSimpleCamera((0.4, 0.6, 6.5), (0, 0, 0), (0, 1, 0), 50.0, W, H, 0.02, 6.5)
+        flat = sc.initKdTree(2).flatten(1)
+        dev = DeviceScene(flat)
+        what = "trial %d scene %d %dx%d spp %dx%d depth %d" % (trial, seed, W, H, sx, sy, depth)
+        full = np.zeros((H, W, 3), np.float32)
+        p = render_params(W, H, sx, sy, max_depth=depth, seed=trial + 1)
+        rs = dev.render(p, full)
+        cpu, crs, _, _ = orc.oracle_render(flat.desc, p, 0, threads=16)
+        assert rs.paths == crs.paths == W * H * sx * sy, what
+        assert np.array_equal(np.isfinite(cpu), np.isfinite(full)), what
+        fin = np.isfinite(cpu).all(axis=2)
+        assert rel_mse(full[fin], cpu[fin]) <= REL_MSE_TOL, what
+        cuts = sorted(set([0, H] + [int(x) for x in rng.integers(0, H + 1, 2)]))
+        tiles = np.zeros_like(full)
+        for b, e in zip(cuts[:-1], cuts[1:]):
+            dev.render(render_params(W, H, sx, sy, max_depth=depth, seed=trial + 1, row_begin=b, row_end=e), tiles)
+        assert np.array_equal(tiles.view(np.uint32), full.view(np.uint32)), what + " rows %s" % cuts
+        cap = int(rng.choice([1, W, W * 3 + 1, 64 * 5, 4096, W * H * 2 + 3]))
+        small = np.zeros_like(full)
+        dev.render(render_params(W, H, sx, sy, max_depth=depth, seed=trial + 1, paths_per_pass=cap), small)
+        assert np.array_equal(np.isfinite(small), np.isfinite(full)) and np.allclose(small[fin], full[fin], rtol=3e-6, atol=1e-7), what + " cap %d" % cap
+        spp = sx * sy
+        chunks = sorted(set([0, spp] + [int(x) for x in rng.integers(0, spp + 1, 2)]))
+        parts = np.zeros_like(full)
+        for b, e in zip(chunks[:-1], chunks[1:]):
+            dev.render(render_params(W, H, sx, sy, max_depth=depth, seed=trial + 1, sample_begin=b, sample_end=e), parts)
+        assert np.allclose(parts[fin], full[fin], rtol=3e-6, atol=1e-7), what + " samples %s" % chunks
+        dev.close()
