@@ -687,3 +687,29 @@ def test_random_frame_shapes_depths_and_splits():
             dev.render(render_params(W, H, sx, sy, max_depth=depth, seed=trial + 1, sample_begin=b, sample_end=e), parts)
         assert np.allclose(parts[fin], full[fin], rtol=3e-6, atol=1e-7), what + " samples %s" % chunks
         dev.close()
+
+
+def test_random_multi_handle_and_progressive_renders(tmp_path):
+    """HIPRenderer over 2-4 handles (mrt_render_multi + mrt_reduce, here all on device 0, more handles
+    than samples included) and in progressive steps with a checkpoint and resume in between, on random
+    scenes, frame shapes, sample grids and depths: the single-handle frame to fp32 addition order,
+    the same statistics."""
+    from tests import fuzz_scenes
+    rng = np.random.default_rng(3)
+    for trial in range(8):
+        seed = int(rng.integers(0, 40))
+        W, H = int(rng.choice([1, 7, 9, 31, 64, 100])), int(rng.choice([1, 5, 17, 48]))
+        sx, sy, depth = int(rng.integers(1, 5)), int(rng.integers(1, 4)), int(rng.integers(0, 6))
+        sc = fuzz_scenes.make_shaded(seed, 0.05, True)
+        sc.setSimpleCamera((0.4, 0.6, 6.5), (0, 0, 0), (0, 1, 0), 50.0, W, H, 0.02, 6.5)
+        one, st1, _ = sc.hip_render(W, H, sx, sy, max_depth=depth, seed=trial + 5)
+        nd = int(rng.integers(2, 5))
+        multi, stm, _ = sc.hip_render(W, H, sx, sy, max_depth=depth, seed=trial + 5, devices=[0] * nd)
+        what = "trial %d scene %d %dx%d spp %dx%d depth %d handles %d" % (trial, seed, W, H, sx, sy, depth, nd)
+        fin = np.isfinite(one).all(axis=2)
+        assert np.array_equal(np.isfinite(one), np.isfinite(multi)) and np.allclose(multi[fin], one[fin], rtol=3e-6, atol=1e-7), what
+        assert (stm.paths, stm.rays_closest, stm.rays_any) == (st1.paths, st1.rays_closest, st1.rays_any), what
+        step = int(rng.integers(1, sx * sy + 1))
+        prog, stp, steps = sc.hip_render_progressive(W, H, sx, sy, step, max_depth=depth, seed=trial + 5, checkpoint_after=int(rng.integers(0, 3)),
+                                                     checkpoint_path=tmp_path / ("c%d.ckpt" % trial))
+        assert np.allclose(prog[fin], one[fin], rtol=3e-6, atol=1e-7), what + " progressive step %d" % step
