@@ -487,3 +487,39 @@ def test_live_reference_functions_on_edge_values(built):
     f, g = draw(0, 10), draw(0, 10)
     o.orc_power_heuristic(n, P(f), P(g), P(a)), r.ref_power_heuristic(n, P(f), P(g), P(b))
     assert same(a, b)
+
+
+@pytest.mark.ref
+def test_live_reference_random_cameras(built):
+    """Container only: 200 random SimpleCamera set-ups (position, target, up vectors that are not
+    unit or not perpendicular, field of view, frame sizes down to one pixel, lens and focus): the
+    parameters the host library and the oracle derive are the reference's bit for bit, and so are the
+    rays the oracle's get_ray makes from them for random film and lens samples."""
+    from raytracer_amd.host import Scene, Transform
+    lib, o = orc.ref(), orc.oracle()
+    rng = np.random.default_rng(1)
+    fields = ("near_top_left", "dx_pixel", "dy_pixel", "x_dir")
+    n = 256
+    for k in range(200):
+        frm, at = (rng.random(3) * 10 - 5).astype(np.float32), (rng.random(3) * 4 - 2).astype(np.float32)
+        up = np.array([0, 1, 0], np.float32) if k % 2 else (rng.random(3) - 0.5).astype(np.float32)
+        fov, lens, focus = float(np.float32(rng.uniform(10, 120))), float(np.float32(rng.uniform(0, 0.1))), float(np.float32(rng.uniform(0.5, 20)))
+        w, h = int(rng.integers(1, 2000)), int(rng.integers(1, 1200))
+        cam = lib.ref_camera_new(P(frm), P(at), P(up), fov, float(w), float(h), lens, focus)
+        want = np.zeros(12, np.float32)
+        lib.ref_camera_params(cam, P(want))
+        sc = Scene()
+        sc.add_sphere(Transform(), sc.CreateMaterial())
+        sc.setSimpleCamera(tuple(map(float, frm)), tuple(map(float, at)), tuple(map(float, up)), fov, w, h, lens, focus)
+        flat = sc.initKdTree(1).flatten(0)
+        c = flat.desc.contents.camera
+        assert np.array_equal(bits(np.concatenate([np.array(getattr(c, f), np.float32) for f in fields])), bits(want)), k
+        oc = abi.Camera()
+        o.orc_camera(P(frm), P(at), P(up), fov, float(w), float(h), lens, focus, C.byref(oc))
+        assert np.array_equal(bits(np.concatenate([np.array(getattr(oc, f), np.float32) for f in fields])), bits(want)), k
+        st = (rng.random((n, 2)) * np.array([w, h])).astype(np.float32)
+        u2 = rng.random((n, 2)).astype(np.float32)
+        ro, rd, oo, od = (np.zeros((n, 3), np.float32) for _ in range(4))
+        lib.ref_camera_rays(cam, n, P(st), P(u2), P(ro), P(rd))
+        o.orc_camera_rays(C.byref(oc), n, P(st), P(u2), P(oo), P(od))
+        assert np.array_equal(bits(oo), bits(ro)) and np.array_equal(bits(od), bits(rd)), k
