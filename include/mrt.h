@@ -237,7 +237,13 @@ typedef struct mrt_render_stats {
  * which the tree's leaves first reference them (so a mesh stored in any order traverses alike); the
  * order inside a leaf's list, which decides ties, is the caller's, and every object index that
  * leaves the library (mrt_hits.prim) is the caller's.  MRT_OBJECT_ORDER=input in the environment
- * keeps the caller's order (measurements only). */
+ * keeps the caller's order (measurements only).
+ * Every index the description carries is checked on the host before the device is touched (tree
+ * children and leaf ranges, one parent per node, depth; leaf references; out-of-tree planes; object
+ * material / transform / kind; material type and texture; texture kind and texel window; light
+ * kind / shape / transform; env_light naming an IBL light): MRT_ERR_INVALID or MRT_ERR_UNSUPPORTED
+ * with a message, MRT_ERR_NOMEM when the host runs out of memory for the tables.  A description that
+ * is accepted cannot make a kernel read outside its tables, whatever its floats hold. */
 mrt_status mrt_scene_create( const mrt_scene_desc* desc, int device, mrt_scene** out );
 void mrt_scene_destroy( mrt_scene* scene );
 
