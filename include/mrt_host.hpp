@@ -198,10 +198,10 @@ void addObjectsFromFile( const char* filename, Scene* scene, Material& default_m
 // building large stress meshes from a small file).
 void addObjectsFromFileEx( const char* filename, Scene* scene, size_t default_mat, Transform& transform, float prescale, int subdivisions );
 
-// parseScene (example_scenes.cpp:1594-1647) over scene data files: the Cook-Torrance scenes 9, 18,
-// 19, 20 and 21 live in <asset_dir>/scenes/scene<N>.scene (format: csrc/host/example_scenes.cpp) and
-// list the reference's calls in the reference's order, so every index comes out the same; an id that
-// names no scene gives scene 19 as in the reference.  Scenes 10-17 (Blinn materials, which the
+// parseScene (example_scenes.cpp:1594-1647) over scene data files: the Cook-Torrance scenes 9, 16,
+// 17, 18, 19, 20 and 21 live in <asset_dir>/scenes/scene<N>.scene (format: csrc/host/example_scenes.cpp)
+// and list the reference's calls in the reference's order, so every index comes out the same; an id
+// that names no scene gives scene 19 as in the reference.  Scenes 10-15 (Blinn materials, which the
 // Pathtracer evaluates to black) throw std::invalid_argument.  width, height: the reference's WIDTH,
 // HEIGHT macros (example_scenes.h:4-5).  asset_dir: null = $MRT_ASSETS, else "../assets".
 Scene* parseScene( int sceneId, int width = 1200, int height = 800, const char* asset_dir = nullptr );

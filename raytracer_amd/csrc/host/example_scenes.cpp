@@ -13,6 +13,8 @@
 //   env FILE                       new IBL(FILE); addLight; envLights.push_back
 //   material NAME [type diffuse|specular|transparent] [albedo R G B] [emission R G B]
 //            [roughness X] [metalness X] [ior X]          scene->CreateMaterial(COOK_TORRANCE, type)
+//   material NAME model blinn      scene->CreateMaterial(BLINN): a place in the material table (scene 17
+//                                  makes one that no object uses); flatten refuses objects that use one
 //   texture NAME image FILE | texture NAME checker R G B R G B
 //   texture_transform NAME <ops>   the texture's m_transform
 //   transform <ops>                the current object transform, built from identity by
@@ -143,6 +145,13 @@ Scene* loadSceneFile( const char* filename, int width, int height, const char* a
             std::string name = tk.word();
             if ( mats.count( name ) ) throw std::runtime_error( tk.where + ": material '" + name + "' defined twice" );
             MatType type = DIFFUSE;
+            if ( tk.more() && tk.peek() == "model" ) { // a Blinn material only takes its place in the table
+                tk.word();
+                tk.expect( "blinn" );
+                mats[name] = scene->CreateMaterial( MaterialModel::BLINN ).m_UID;
+                if ( tk.more() ) throw std::runtime_error( tk.where + ": a Blinn material takes no fields" );
+                continue;
+            }
             if ( tk.more() && tk.peek() == "type" ) {
                 tk.word();
                 std::string t = tk.word();
@@ -223,6 +232,8 @@ Scene* parseScene( int sceneId, int width, int height, const char* asset_dir ) {
         sceneId = 19;
         // fall through
     case 9:
+    case 16:
+    case 17:
     case 18:
     case 19:
     case 20:
@@ -234,8 +245,6 @@ Scene* parseScene( int sceneId, int width, int height, const char* asset_dir ) {
     case 13:
     case 14:
     case 15:
-    case 16:
-    case 17:
         // Blinn materials under point / directional / ambient lights, written for the Whitted
         // integrator that the reference has switched off; its Pathtracer evaluates a Blinn material
         // to black (Material.cpp:1011, 1098), so there is nothing for this backend to render.

@@ -233,6 +233,10 @@ FlatScene* flatten( Scene* scene, KdTree* tree, NodeLayout layout ) {
         fs->obj_material[i]  = (uint32_t)o->m_MaterialIndex;
         fs->obj_transform[i] = tt.intern( o->transform );
         if ( o->m_MaterialIndex >= scene->m_Materials.size() ) throw std::runtime_error( "flatten: material index out of range" );
+        // the reference's path tracer evaluates a Blinn material to black (Material.cpp:1011, 1098) and leaves
+        // the sampled direction unset; the kernels implement the Cook-Torrance model only
+        if ( scene->m_Materials[o->m_MaterialIndex].m_MatModel != MaterialModel::COOK_TORRANCE )
+            throw std::runtime_error( "flatten: object " + std::to_string( i ) + " uses a Blinn material, which the GPU backend does not shade" );
         if ( o->geom.type == TRIANGLE ) {
             const auto& t = o->geom.triangle;
             put3( &fs->tri_p[9 * i], t.p1 );

@@ -24,7 +24,7 @@ def asset(name):
 
 def parse_scene(scene_id, width=1200, height=800):
     """parseScene(sceneId) of the reference (example_scenes.cpp:1594-1647) for its Cook-Torrance scenes
-    9, 18, 19, 20 and 21, read from assets/scenes/scene<N>.scene; 1200x800 are the reference's WIDTH and
+    9, 16, 17, 18, 19, 20 and 21, read from assets/scenes/scene<N>.scene; 1200x800 are the reference's WIDTH and
     HEIGHT (example_scenes.h:4-5)."""
     return Scene.parse(scene_id, width, height, ASSETS)
 

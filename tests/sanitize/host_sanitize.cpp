@@ -199,7 +199,7 @@ int main( int argc, char** argv ) {
     }
     {
         // parseScene over the scene data files, and a file with an error in it
-        for ( int id : { 9, 18, 19, 20, 21 } ) {
+        for ( int id : { 9, 16, 17, 18, 19, 20, 21 } ) {
             Scene* scene = parseScene( id, 120, 80, assets.c_str() );
             CHECK( scene && scene->cam && !scene->objects.empty() );
             KdTree* tree = initKdTree( scene, 2 );
@@ -267,7 +267,7 @@ int main( int argc, char** argv ) {
     }
     {
         // scene data files with damaged text: a scene or an exception, never a sanitizer report
-        for ( int id : { 9, 18, 21 } ) {
+        for ( int id : { 9, 17, 18, 21 } ) {
             std::ifstream f( assets + "/scenes/scene" + std::to_string( id ) + ".scene", std::ios::binary );
             const std::string text( ( std::istreambuf_iterator<char>( f ) ), std::istreambuf_iterator<char>() );
             CHECK( text.size() > 100 );

@@ -1,5 +1,5 @@
 """parseScene over the scene data files (assets/scenes/scene<N>.scene): the reference's Cook-Torrance
-example scenes 9, 18, 19, 20, 21 (example_scenes.cpp:155-225, 1164-1592).
+example scenes 9, 16, 17, 18, 19, 20, 21 (example_scenes.cpp:155-225, 910-1592).
 
 The reference's example_scenes.cpp cannot be built in the container (it includes Light.h, which
 needs a header that is not in the image), so the scene files are transcriptions checked here against
@@ -174,8 +174,70 @@ def test_scene19_float_loops(built):
     assert_same_tables(a, b)
 
 
+def _box_scene(which):
+    """Scenes 16 and 17 assembled call by call (example_scenes.cpp:910-1030, 1032-1162)."""
+    sc = Scene()
+    box = [("mat", [("scale", 32, 32, 32), ("translate", 0, 0, 12), ("translate", 0, 0, -12)]),
+           ("mat", [("scale", 32, 32, 32), ("rotate", 1, 0, 0, 180.0), ("translate", 0, 0, 12), ("translate", 0, 0, 12)]),
+           ("mat", [("scale", 32, 32, 32), ("rotate", 1, 0, 0, 90.0), ("translate", 0, 0, 12), ("translate", 0, 20, 0)]),
+           ("mat1", [("scale", 32, 32, 32), ("rotate", 0, 1, 0, 90.0), ("translate", 0, 0, 12), ("translate", -15, 0, 0)]),
+           ("mat2", [("scale", 32, 32, 32), ("rotate", 0, 1, 0, -90.0), ("translate", 0, 0, 12), ("translate", 15, 0, 0)])]
+    ball = [("scale", 4.5, 4.5, 4.5), ("rotate", 0, 0, 1, 150.0), ("rotate", 0, 1, 0, 30.0)]
+    m = {}
+    if which == 16:
+        sc.setSimpleCamera((0., -60, 16), (0, 0, 11), (0, 0.0, 1), 30, 1200, 800, 0, 1)
+        m["mat"] = sc.CreateMaterial(albedo=(1, 1, 1), metalness=0.0, roughness=1.0)
+    else:
+        frm, at = np.array((0., -60, 16), np.float32), np.array((0, 0, 11), np.float32)
+        d = at - frm
+        focus = np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])  # glm::length: sqrt(dot), fp32, unfused
+        sc.setSimpleCamera((0., -60, 16), (0, 0, 11), (0, 0.0, 1), 30, 1200, 800, 0.001, float(focus))
+        m["mat"] = sc.CreateMaterial(albedo=(0.8, 0.8, 0.8), metalness=0.0, roughness=1.0)
+    for name, ops in box:
+        if name not in m:
+            m[name] = sc.CreateMaterial(albedo={"mat1": (1, 0.2, 0.2), "mat2": (0.8, 0.2, 0.2) if which == 16 else (0.2, 0.2, 1.0)}[name],
+                                        metalness=0.0, roughness=1.0)
+        sc.add_plane(cases.transform_from_ops(ops), m[name])
+    if which == 16:
+        sc.CreateMaterial(albedo=(0.8, 0.2, 0.2), metalness=0.0, roughness=1.0)  # mat3, unused
+        mat4 = sc.CreateMaterial(albedo=(0.0, 1., 0.0), metalness=0.0, roughness=0.4)
+        sc.add_sphere(cases.transform_from_ops(ball + [("translate", 8, -6, 4.5)]), mat4)
+        size, power, at_z = 3.0, 10.0, 19
+    else:
+        mat3 = sc.CreateMaterial(abi.MRT_MAT_SPECULAR, albedo=(0.6, 0.2, 0.2), roughness=0.5, ior=1.01)
+        mat4 = sc.CreateMaterial(abi.MRT_MAT_TRANSPARENT, albedo=(1, 1, 1), ior=1.5)
+        sc.add_sphere(cases.transform_from_ops(ball + [("translate", 0, -2, 13.5)]), mat4)
+        sc.add_sphere(cases.transform_from_ops(ball + [("translate", -8, -6, 8.5)]), mat3)
+        size, power, at_z = 0.9, 4.0, 5
+    mat_e = sc.CreateMaterial(emission=(power,) * 3, albedo=(1, 1, 1))
+    xf = cases.transform_from_ops([("scale", size, size, size), ("translate", 0, 0, at_z)])
+    sc.add_sphere(xf, mat_e)
+    sc.add_sphere_light(xf, mat_e, (power,) * 3)
+    return sc
+
+
+def test_scene16_equals_the_call_by_call_assembly(built):
+    a, _ = tables(scenes.parse_scene(16))
+    b, _ = tables(_box_scene(16))
+    assert_same_tables(a, b)
+    assert tuple(a["counts"][[0, 2, 7, 8]]) == (7, 6, 5, 1)  # objects, materials, out-of-tree planes, lights
+
+
+def test_scene17_equals_the_call_by_call_assembly(built):
+    """Scene 17's file also makes the Blinn material the reference creates for its back wall and then
+    does not use (the wall is made with `mat`): it takes index 1 of the material table, every later
+    index is one higher than in the assembly without it."""
+    a, _ = tables(scenes.parse_scene(17))
+    b, _ = tables(_box_scene(17))
+    assert tuple(a["counts"][[0, 2, 7, 8]]) == (8, 7, 5, 1) and b["counts"][2] == 6
+    words = C.sizeof(abi.Material) // 4
+    assert np.array_equal(a["materials"][:words], b["materials"][:words]) and np.array_equal(a["materials"][2 * words:], b["materials"][words:])
+    assert np.array_equal(a["obj_material"], np.where(b["obj_material"] >= 1, b["obj_material"] + 1, b["obj_material"]))
+    assert_same_tables(a, b, skip=("counts", "materials", "obj_material"))
+
+
 def test_blinn_scenes_and_bad_files_are_refused(built, tmp_path):
-    for k in range(10, 18):
+    for k in range(10, 16):
         with pytest.raises(MrtError, match="Blinn"):
             scenes.parse_scene(k)
     bad = tmp_path / "scenes"
