@@ -721,3 +721,53 @@ def test_random_multi_handle_and_progressive_renders(tmp_path):
         prog, stp, steps = sc.hip_render_progressive(W, H, sx, sy, step, max_depth=depth, seed=trial + 5, checkpoint_after=int(rng.integers(0, 3)),
                                                      checkpoint_path=tmp_path / ("c%d.ckpt" % trial))
         assert np.allclose(prog[fin], one[fin], rtol=3e-6, atol=1e-7), what + " progressive step %d" % step
+
+
+def test_asynchronous_renders_on_different_streams_are_ordered():
+    """mrt_render without statistics on device buffers returns before its work has run.  Two such
+    calls on different streams, with an mrt_intersect between them, share the handle's workspace and
+    counters: the library orders them (an event per call), so each image equals the one a
+    synchronous call makes."""
+    import ctypes as C
+    import torch
+    lib = abi.hip()
+    sc = scenes.small_bunny(96, 64, env_pixels=scenes.synthetic_env())
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    pa, pb = render_params(96, 64, 4, 2, max_depth=4, seed=11), render_params(96, 64, 2, 2, max_depth=5, seed=12, paths_per_pass=96 * 8 * 4)
+
+    def render(p, img, stream):
+        st = lib.mrt_render(dev._h, C.byref(p), img.data_ptr(), abi.MRT_BUF_DEVICE, stream, None)
+        assert st == abi.MRT_OK, lib.mrt_last_error().decode()
+
+    want_a, want_b = torch.zeros((64, 96, 3), device="cuda"), torch.zeros((64, 96, 3), device="cuda")
+    render(pa, want_a, None)
+    torch.cuda.synchronize()
+    render(pb, want_b, None)
+    torch.cuda.synchronize()
+    n = 50000
+    rng = np.random.default_rng(4)
+    o = (rng.random((n, 3)) * 2 - 1).astype(np.float32) * 3
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    cols = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (o[:, 0], o[:, 1], o[:, 2], d[:, 0], d[:, 1], d[:, 2],
+                                                                       np.zeros(n, np.float32), np.full(n, 1e4, np.float32))]
+    rays = abi.Rays(*[c.data_ptr() for c in cols])
+
+    def intersect(stream):
+        out = [torch.full((n,), -7, dtype=torch.int32, device="cuda")] + [torch.full((n,), -7.0, device="cuda") for _ in range(3)]
+        hits = abi.Hits(*[t.data_ptr() for t in out])
+        assert lib.mrt_intersect(dev._h, n, C.byref(rays), C.byref(hits), abi.MRT_CLOSEST_HIT, abi.MRT_BUF_DEVICE, stream, None) == abi.MRT_OK
+        return out
+    want_hits = intersect(None)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        a, b = torch.zeros_like(want_a), torch.zeros_like(want_b)
+        torch.cuda.synchronize()
+        render(pa, a, s1.cuda_stream)
+        hits = intersect(s2.cuda_stream)
+        render(pb, b, s2.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(a, want_a) and torch.equal(b, want_b)
+        assert all(torch.equal(g, w) for g, w in zip(hits, want_hits))
+    dev.close()
