@@ -659,6 +659,10 @@ inline uint32_t trace_grid_blocks( Kernel kernel, uint64_t n, int n_cus ) {
     if ( per_cu == 0 ) {
         int v = 0;
         if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &v, kernel, MRT_TRACE_BLOCK, 0 ) != hipSuccess || v < 1 ) v = 1;
+        if ( const char* e = std::getenv( "MRT_TRACE_BLOCKS_PER_CU" ) ) { // measurements: fewer resident blocks than fit
+            const int want = std::atoi( e );
+            if ( want >= 1 && want < v ) v = want;
+        }
         per_cu = v;
     }
     const uint64_t full = (uint64_t)n_cus * (uint64_t)per_cu;
