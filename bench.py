@@ -82,7 +82,10 @@ def profile_gather_ceiling(workload, kernel):
             g = json.load(f)
         k = g["kernels"][kernel]
         return {"l2_requests_G_per_s": k["g_requests_per_s"], "l2_hit_rate": k["l2_hit_rate"], "ceiling_G_per_s": k["ceiling_g_per_s"],
-                "frac": k["fraction"], "model": g["model"]}
+                "frac": k["fraction"], "model": g["model"],
+                "source": "not measured in this run: the request rate and hit rate are from the committed counter passes of this workload "
+                          "(profiles/r02_million_bunny_mem_pipe.json, r02_million_bunny_pmc_summary.json), the gather rates from "
+                          "profiles/r02_gather_ceiling.txt (raytracer_amd/gather_bench)"}
     except Exception:
         return None
 
