@@ -61,4 +61,17 @@ for k, c in pmc.items():
 allw["workloads"][workload] = w
 with open(path, "w") as f:
     json.dump(allw, f, indent=1)
+# The bench line of the trace run read the counter traffic from the hbm_traffic.json of the run
+# before; bring its copy in profiles/ in step with the passes just collected.
+bench_path = os.path.join(dst, base + "_bench.json")
+line = json.loads(open(bench_path).read())
+roof = line.get("roofline") or {}
+kernel = (roof.get("kernel") or "").split(" ")[0]
+if kernel in w["bytes_per_launch"] and roof.get("avg_launch_ms"):
+    roof["traffic"] = w["bytes_per_launch"][kernel]
+    roof["hbm_frac_from_counters"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / roof["peak"]
+    if kernel in w["tcc_hit_rate"]:
+        roof["limiter"] = "L2 / memory-side-cache gather latency (TCC hit rate %.2f)" % w["tcc_hit_rate"][kernel]
+    with open(bench_path, "w") as f:
+        f.write(json.dumps(line) + "\n")
 print("profiles written for", tag, workload)
