@@ -26,7 +26,10 @@ REF_SO = os.path.join(ORACLE, "_ref", "libmrt_ref.so")
 
 # -ffp-contract=off is a correctness flag here: primitive ids are bit-identical to the CPU
 # reference only with unfused fp32 arithmetic.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
+# -fno-slp-vectorize: the SLP vectorizer pairs the kernels' fp32 arithmetic into packed instructions,
+# which costs register pairs and moves: without it the traversal kernels need 55-66 instead of 70-78
+# registers and the frame is 4 % faster (same bits: packed and scalar fp32 operations round alike).
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared"]
 HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fno-fast-math"]
 
 
@@ -56,7 +59,7 @@ def _run(cmd):
 
 def build_hip(force=False):
     srcs = _files(CSRC, (".hip", ".hpp", ".inc")) + _files(INC, (".h",))
-    srcs = [s for s in srcs if os.sep + "host" + os.sep not in s]
+    srcs = [s for s in srcs if os.sep + "host" + os.sep not in s] + [os.path.abspath(__file__)]  # the flags live in this file
     if force or _newer(HIP_SO, srcs):
         _run(["hipcc"] + HIP_FLAGS + ["-I" + INC, "-o", HIP_SO, os.path.join(CSRC, "mrt_hip.hip")])
     return HIP_SO
@@ -65,7 +68,7 @@ def build_hip(force=False):
 def build_host(force=False):
     host_dir = os.path.join(CSRC, "host")
     srcs = _files(host_dir, (".cpp",))
-    deps = srcs + _files(host_dir, (".hpp",)) + _files(INC, (".h", ".hpp")) + [HIP_SO]
+    deps = srcs + _files(host_dir, (".hpp",)) + _files(INC, (".h", ".hpp")) + [HIP_SO, os.path.abspath(__file__)]
     if force or _newer(HOST_SO, deps):
         _run(["g++"] + HOST_FLAGS + ["-I" + INC, "-I" + host_dir, "-o", HOST_SO] + srcs +
              ["-L" + PKG, "-lmrt_hip", "-Wl,-rpath,$ORIGIN"])

@@ -18,5 +18,5 @@ if [ "$1" = "--from" ]; then
   set --
 fi
 mkdir -p raytracer_amd/ab
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -shared -I$root/include "$@" -o raytracer_amd/ab/$name.so $root/raytracer_amd/csrc/mrt_hip.hip
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -shared -I$root/include "$@" -o raytracer_amd/ab/$name.so $root/raytracer_amd/csrc/mrt_hip.hip
 echo built raytracer_amd/ab/$name.so
