@@ -373,7 +373,15 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         sp++;
     };
 
+#ifdef MRT_EXTRA_VALU
+    float extra_valu = 1.f; // measurement aid: MRT_EXTRA_VALU more vector-ALU instructions per trip
+#endif
     for ( ;; ) {
+#ifdef MRT_EXTRA_VALU
+#pragma unroll
+        for ( int i = 0; i < MRT_EXTRA_VALU; i++ )
+            asm volatile( "v_add_f32 %0, %0, %0" : "+v"( extra_valu ) );
+#endif
         // ---------------------------------------------------------------- refill
         const unsigned long long idle = __ballot( state == MRT_ST_IDLE );
         const uint32_t n_idle         = (uint32_t)__popcll( idle );
