@@ -354,6 +354,14 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
     if ( have ) {
         // a path's first shade starts from radiance 0, throughput 1 and nothing pending
         V3 L = mk3( 0.f ), tp = mk3( 1.f );
+#ifdef MRT_EXTRA_VALU_SHADE
+        { // measurement aid: that many more vector-ALU instructions per shaded path
+            float extra_valu = 1.f;
+#pragma unroll
+            for ( int i = 0; i < MRT_EXTRA_VALU_SHADE; i++ )
+                asm volatile( "v_add_f32 %0, %0, %0" : "+v"( extra_valu ) );
+        }
+#endif
         if ( depth != 0 ) {
             L = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
             fold_pending( ps, id, L );
