@@ -580,6 +580,22 @@ struct MisOcclusionIO {
         if ( !found ) ( (uint8_t*)ps.pending )[4u * id + 2u] = 1;
     }
 };
+#ifdef MRT_REFILL_MIN_CAMERA // measurement aids: refill thresholds per ray source
+template <>
+struct RefillMin<CameraIO> {
+    static constexpr uint32_t value = MRT_REFILL_MIN_CAMERA;
+};
+#endif
+#ifdef MRT_REFILL_MIN_OCCLUSION
+template <>
+struct RefillMin<ShadowIO> {
+    static constexpr uint32_t value = MRT_REFILL_MIN_OCCLUSION;
+};
+template <>
+struct RefillMin<MisOcclusionIO> {
+    static constexpr uint32_t value = MRT_REFILL_MIN_OCCLUSION;
+};
+#endif
 
 template <bool STATS>
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_occlusion_kernel( DTrace tr, MisOcclusionIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {

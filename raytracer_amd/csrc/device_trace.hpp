@@ -53,6 +53,11 @@
 #ifndef MRT_REFILL_MIN
 #define MRT_REFILL_MIN 16 // idle lanes that trigger a refill of the wave
 #endif
+// per ray source (the IO type of trace_stream): specialised where a source wants another threshold
+template <class IO>
+struct RefillMin {
+    static constexpr uint32_t value = MRT_REFILL_MIN;
+};
 
 // prim record: 3 x float4 in a 64-byte slot (a record never straddles two cache lines)
 //   q0 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane),
@@ -386,7 +391,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         const unsigned long long idle = __ballot( state == MRT_ST_IDLE );
         const uint32_t n_idle         = (uint32_t)__popcll( idle );
         if ( !more && n_idle == 64u ) break;
-        if ( more && n_idle >= MRT_REFILL_MIN ) {
+        if ( more && n_idle >= RefillMin<IO>::value ) {
             while ( left == 0 && part_try < 8u ) {
                 const uint32_t part = ( ( blockIdx.x & s.xcd_mask ) + part_try ) & 7u;
                 uint32_t got        = 0;
