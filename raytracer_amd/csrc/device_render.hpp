@@ -577,7 +577,7 @@ struct MisOcclusionIO {
     }
     // an escaped ray makes the contribution shade computed for that case: one byte tells the fold
     MRT_DEV void store( uint32_t id, bool found, const DHit& ) const {
-        if ( !found ) ( (uint8_t*)ps.pending )[4u * id + 2u] = 1;
+        if ( !found ) ( (uint8_t*)ps.pending )[(size_t)4 * id + 2u] = 1;
     }
 };
 #ifdef MRT_REFILL_MIN_CAMERA // measurement aids: refill thresholds per ray source
