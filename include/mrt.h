@@ -365,7 +365,19 @@ typedef struct mrt_device_info {
 } mrt_device_info;
 mrt_status mrt_scene_device_info( const mrt_scene* scene, mrt_device_info* out );
 
+/* Diagnostics: the number of rays this handle's traversal launches have handed over to follow-up
+ * launches so far (waits for the device).  A traversal launch lasts as long as its longest ray, so a
+ * ray still in flight some hundred trips after the launch's list ran out is handed over at the next
+ * leaf boundary and the rest of its interval is traced as several shorter rays side by side; the
+ * result is the same hit.  MRT_RELAY=0 in the environment when the scene is created switches this
+ * off, MRT_RELAY_AFTER=<trips> sets how long a wave goes on first (default 256; 0 in the tests). */
+mrt_status mrt_debug_relayed( mrt_scene* scene, uint64_t* out );
+
 const char* mrt_last_error( void );
+/* The version of this header the library was built from (MRT_VERSION).  2: mrt_render_stats ends
+ * with `passes` (a caller built against version 1 must not pass its shorter struct), mrt_scene_trim,
+ * mrt_debug_relayed. */
+#define MRT_VERSION 2
 int32_t mrt_version( void );
 
 #ifdef __cplusplus

@@ -62,16 +62,16 @@ MRT_DEV void get_ray( const float4* r0, const float4* r1, uint32_t id, V3& o, V3
     tmax = b.z;
 }
 MRT_DEV void put_hit( float4* hit, uint32_t id, const DHit& h ) {
-    const uint32_t bits = h.prim < 0 ? 0xffffffffu : ( (uint32_t)h.prim | ( h.outside ? 0x80000000u : 0u ) );
-    hit[id]             = make_float4( __uint_as_float( bits ), h.t, h.u, h.v );
+    hit[id] = pack_hit( h );
 }
 MRT_DEV void get_hit( const float4* hit, uint32_t id, DHit& h ) {
-    const float4 r      = hit[id];
-    const uint32_t bits = __float_as_uint( r.x );
-    h.prim              = bits == 0xffffffffu ? -1 : (int32_t)( bits & 0x7fffffffu );
-    h.outside           = bits == 0xffffffffu ? 0u : bits >> 31;
-    h.t = r.y, h.u = r.z, h.v = r.w;
+    unpack_hit( hit[id], h );
 }
+// The rays of one of the three ray record pairs, by path id (what a relay launch reads them through).
+struct PathRays {
+    const float4 *r0, *r1;
+    MRT_DEV void reload( uint32_t id, V3& o, V3& d, float& tmax ) const { get_ray( r0, r1, id, o, d, tmax ); }
+};
 
 struct PassInfo {
     uint32_t width;
@@ -200,6 +200,8 @@ struct ExtendIO {
         t0 = 0.f;
     }
     MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
+    MRT_DEV void reload( uint32_t id, V3& o, V3& d, float& t1 ) const { get_ray( ps.ray0, ps.ray1, id, o, d, t1 ); }
+    PathRays rays() const { return PathRays { ps.ray0, ps.ray1 }; }
 };
 
 // The first bounce makes its camera rays itself: the ray of path i -- Sampler::GetCameraSample
@@ -228,24 +230,27 @@ struct CameraIO {
         put_ray( ps.ray0, ps.ray1, id, o, d, t1 );
     }
     MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
+    // the ray load() stored
+    MRT_DEV void reload( uint32_t id, V3& o, V3& d, float& t1 ) const { get_ray( ps.ray0, ps.ray1, id, o, d, t1 ); }
+    PathRays rays() const { return PathRays { ps.ray0, ps.ray1 }; }
 };
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_camera_kernel( DTrace tr, CameraIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_camera_kernel( DTrace tr, CameraIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
-    trace_stream<false, false, STATS>( tr, lp, io, n, deal, st );
+    trace_stream<false, false, STATS>( tr, lp, io, n, deal, st, relay );
     if ( STATS ) flush_stats( st, stats );
 }
 
 // STATS (all traversal kernels of this file): also count the visited nodes, leaves, references
 // and primitive tests into stats[0..3].
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_kernel( DTrace tr, ExtendIO io, const uint32_t* __restrict__ n_ptr, uint32_t n_max, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
-    trace_stream<false, false, STATS>( tr, lp, io, n_ptr ? *n_ptr : n_max, deal, st );
+    trace_stream<false, false, STATS>( tr, lp, io, n_ptr ? *n_ptr : n_max, deal, st, relay );
     if ( STATS ) flush_stats( st, stats );
 }
 
@@ -527,14 +532,16 @@ struct ShadowIO {
     MRT_DEV void store( uint32_t id, bool occluded, const DHit& ) const {
         if ( occluded ) ps.dix[id] = ps.diy[id] = ps.diz[id] = 0.f;
     }
+    MRT_DEV void reload( uint32_t id, V3& o, V3& d, float& t1 ) const { get_ray( ps.sray0, ps.sray1, id, o, d, t1 ); }
+    PathRays rays() const { return PathRays { ps.sray0, ps.sray1 }; }
 };
 
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( true )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
-    trace_stream<true, true, STATS>( tr, lp, io, *count, deal, st );
+    trace_stream<true, true, STATS>( tr, lp, io, *count, deal, st, relay );
     if ( STATS ) flush_stats( st, stats );
 }
 
@@ -550,14 +557,16 @@ struct MisIO {
         t0 = 0.f;
     }
     MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
+    MRT_DEV void reload( uint32_t id, V3& o, V3& d, float& t1 ) const { get_ray( ps.mray0, ps.mray1, id, o, d, t1 ); }
+    PathRays rays() const { return PathRays { ps.mray0, ps.mray1 }; }
 };
 
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_kernel( DTrace tr, MisIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
-    trace_stream<false, false, STATS>( tr, lp, io, *count, deal, st );
+    trace_stream<false, false, STATS>( tr, lp, io, *count, deal, st, relay );
     if ( STATS ) flush_stats( st, stats );
 }
 
@@ -579,6 +588,8 @@ struct MisOcclusionIO {
     MRT_DEV void store( uint32_t id, bool found, const DHit& ) const {
         if ( !found ) ( (uint8_t*)ps.pending )[(size_t)4 * id + 2u] = 1;
     }
+    MRT_DEV void reload( uint32_t id, V3& o, V3& d, float& t1 ) const { get_ray( ps.mray0, ps.mray1, id, o, d, t1 ); }
+    PathRays rays() const { return PathRays { ps.mray0, ps.mray1 }; }
 };
 #ifdef MRT_REFILL_MIN_CAMERA // measurement aids: refill thresholds per ray source
 template <>
@@ -598,11 +609,11 @@ struct RefillMin<MisOcclusionIO> {
 #endif
 
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_occlusion_kernel( DTrace tr, MisOcclusionIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_occlusion_kernel( DTrace tr, MisOcclusionIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( true )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
-    trace_stream<true, true, STATS>( tr, lp, io, *count, deal, st );
+    trace_stream<true, true, STATS>( tr, lp, io, *count, deal, st, relay );
     if ( STATS ) flush_stats( st, stats );
 }
 

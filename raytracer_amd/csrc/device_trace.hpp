@@ -43,6 +43,9 @@
 #pragma once
 #include "device_math.hpp"
 
+#include <cstdlib>
+#include <mutex>
+
 #ifndef MRT_STACK_MAX
 #define MRT_STACK_MAX 128 // deferred nodes per ray: trees up to depth 126 (the entries beyond the LDS part live in scratch)
 #endif
@@ -115,6 +118,11 @@ struct DHit {
 struct DStats {
     uint32_t inner, leaves, refs, tests;
 };
+#ifdef MRT_TRIP_HISTOGRAM
+// measurement aid: how many trips of the wave's loop the rays stayed in flight, in powers of two
+// (bucket k: 2^k <= trips < 2^(k+1)); read and cleared by mrt_debug_trip_histogram
+__device__ unsigned long long g_trip_hist[32];
+#endif
 
 // LDS of a traversal block (MRT_TRACE_BLOCK lanes).  Everything a lane touches rarely lives here
 // instead of in registers, slot-major so that the lanes of a wave fall on distinct banks:
@@ -262,26 +270,30 @@ MRT_DEV bool plane_test( V3 origin, V3 dir, float tmax, float& t, float& u, floa
     return true;
 }
 
-// intersectAabb on the root box (kdtree.cpp:162-180): clips [ray_tmin, ray_tmax], false on a miss.
-MRT_DEV bool clip_root( const DTrace& s, V3 o, V3 d, float& ray_tmin, float& ray_tmax ) {
-    if ( s.n_nodes == 0 ) return false;
+// intersectAabb (kdtree.cpp:162-180) on the box [bmin, bmax]: clips [ray_tmin, ray_tmax], false on a miss.
+MRT_DEV bool clip_box( const float* bmin, const float* bmax, V3 o, V3 d, float& ray_tmin, float& ray_tmax ) {
     const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
     const bool sx = !( d.x >= 0 ), sy = !( d.y >= 0 ), sz = !( d.z >= 0 );
-    float tmin  = ( ( sx ? s.root_max[0] : s.root_min[0] ) - o.x ) * ix;
-    float tmax  = ( ( sx ? s.root_min[0] : s.root_max[0] ) - o.x ) * ix;
-    float tymin = ( ( sy ? s.root_max[1] : s.root_min[1] ) - o.y ) * iy;
-    float tymax = ( ( sy ? s.root_min[1] : s.root_max[1] ) - o.y ) * iy;
+    float tmin  = ( ( sx ? bmax[0] : bmin[0] ) - o.x ) * ix;
+    float tmax  = ( ( sx ? bmin[0] : bmax[0] ) - o.x ) * ix;
+    float tymin = ( ( sy ? bmax[1] : bmin[1] ) - o.y ) * iy;
+    float tymax = ( ( sy ? bmin[1] : bmax[1] ) - o.y ) * iy;
     if ( ( tmin > tymax ) || ( tymin > tmax ) ) return false;
     if ( tymin > tmin ) tmin = tymin;
     if ( tymax < tmax ) tmax = tymax;
-    float tzmin = ( ( sz ? s.root_max[2] : s.root_min[2] ) - o.z ) * iz;
-    float tzmax = ( ( sz ? s.root_min[2] : s.root_max[2] ) - o.z ) * iz;
+    float tzmin = ( ( sz ? bmax[2] : bmin[2] ) - o.z ) * iz;
+    float tzmax = ( ( sz ? bmin[2] : bmax[2] ) - o.z ) * iz;
     if ( ( tmin > tzmax ) || ( tzmin > tmax ) ) return false;
     if ( tzmin > tmin ) tmin = tzmin;
     if ( tzmax < tmax ) tmax = tzmax;
     if ( tmin > ray_tmin ) ray_tmin = tmin;
     if ( tmax < ray_tmax ) ray_tmax = tmax;
     return true;
+}
+// The same on the (padded) root box of the tree.
+MRT_DEV bool clip_root( const DTrace& s, V3 o, V3 d, float& ray_tmin, float& ray_tmax ) {
+    if ( s.n_nodes == 0 ) return false;
+    return clip_box( s.root_min, s.root_max, o, d, ray_tmin, ray_tmax );
 }
 
 // Lane states of the streaming traversal.
@@ -299,6 +311,54 @@ MRT_DEV uint32_t ld_ref( const DTrace& s, uint32_t i ) {
 }
 MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
     return *(const float4*)( (const char*)s.prims + ( obj * ( MRT_PRIM_Q * 16u ) + k * 16u ) );
+}
+
+// The out-of-tree planes of a ray (kdtree.cpp:563-611), tested when the ray is fetched: an any-hit ray
+// stops at the first plane accepted within its interval; a closest-hit ray takes the nearest one,
+// the first on ties (how far it may lie is only known when the ray retires: merge_plane).  Returns
+// whether a plane was hit, its record (prim, t, u, v) in `rec`, and in `tested` the number of planes
+// the reference would have tested.
+template <bool ANY>
+MRT_DEV bool scan_planes( const DTrace& s, const lds_f32* xf_lds, V3 o, V3 d, float ray_tmax, v4f& rec, uint32_t& tested ) {
+    bool has_pl = false;
+    float btmax = ANY ? ray_tmax : __uint_as_float( 0x7f800000u );
+    tested      = s.n_out;
+    rec         = mk4( 0.f, 0.f, 0.f, 0.f );
+    for ( uint32_t k = 0; k < s.n_out; k++ ) {
+        const uint32_t po = s.out_of_tree[k];
+        const uint32_t xf = __float_as_uint( ld_prim( s, po, 0 ).w ) >> MRT_PRIM_XF_SHIFT;
+        V3 oo = o, od = d;
+        if ( xf != 0 ) transform_ray( s, xf_lds, xf, o, d, oo, od );
+        float t, u, v;
+        if ( plane_test( oo, od, btmax, t, u, v ) ) {
+            btmax = t; // accepted: later planes must be at least as near,
+            // and replace this one only if strictly nearer
+            if ( !has_pl || t < rec.y ) rec = mk4( __uint_as_float( po ), t, u, v );
+            has_pl = true;
+            if ( ANY ) {
+                tested = k + 1;
+                break;
+            }
+        }
+    }
+    return has_pl;
+}
+
+// What a ray reports when it leaves the tree with (`has`: hit record in h, h.t = its distance) or
+// without a tree hit (h.prim = -1, h.t = the tmax the ray came with), given the plane record of
+// scan_planes.  A closest-hit ray: the plane must lie within the tree hit distance or, without a tree
+// hit, within the ray's own tmax (h.t in both cases), and replaces a tree hit only if strictly
+// nearer.  An any-hit ray: only without a tree hit.  Returns `found`.
+template <bool ANY>
+MRT_DEV bool merge_plane( bool has, DHit& h, bool has_pl, v4f r ) {
+    bool found = has;
+    if ( has_pl ) {
+        if ( ANY ? !has : ( has ? r.y < h.t : !( r.y > h.t ) ) ) {
+            h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
+            found  = true;
+        }
+    }
+    return found;
 }
 
 // Traces rays 0..n-1 of `io` with the whole grid.
@@ -325,8 +385,34 @@ MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
 #endif
 #define MRT_DEAL_STRIDE 32u
 #define MRT_DEAL_WORDS ( 8u * MRT_DEAL_STRIDE )
+// Relay of long rays.  A launch lasts as long as its longest ray, and one ray in some thousands takes
+// thousands of trips (it runs along a surface through hundreds of small leaves) where the median takes
+// fifty: the waves that hold such rays keep the launch alive for milliseconds after the list ran out.
+// So a ray that is still in flight `after` trips after its wave found the list exhausted is handed over
+// the next time it has finished a leaf without a hit: (tag, exit distance of that leaf) goes to `list`.
+// Everything in front of that distance has been searched, so what remains is the same ray restarted from
+// the root with that distance as its tmin; a follow-up launch (relay_trace_kernel) cuts the remaining
+// interval into MRT_RELAY_K segments, traces the segments as rays of their own, side by side, and
+// relay_finish_kernel takes the first segment that found something.  Same result: the reference accepts
+// a hit where its distance lies within the (closed) interval the ray spends in a leaf, those intervals
+// follow one another along the ray, and the segments cut them at common points, so the first leaf with
+// an accepted hit, and the nearest accepted hit in it, are found by the first segment that reaches
+// into that leaf's part in front of and including the hit -- except where arithmetic on NaN decides (a
+// ray with a zero or non-finite component is never handed over) and for any-hit rays in a scene with
+// emissive objects, whose ignored hits shrink the interval for the rest of the leaf (the host does
+// not enable the relay for them).  list == nullptr: no relay.
+#ifndef MRT_RELAY_K
+#define MRT_RELAY_K 8u // segments per relayed ray (a power of two)
+#endif
+struct Relay {
+    uint2* list;     // (tag, bits of the distance reached)
+    uint32_t* count; // entries appended (may run past cap: the surplus was not handed over)
+    uint32_t cap;
+    uint32_t after;  // trips a wave goes on after the list ran out before it hands its rays over
+};
+
 template <bool ANY, bool BOOL_ONLY, bool STATS, class IO>
-MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t n, uint32_t* deal, DStats& st ) {
+MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t n, uint32_t* deal, DStats& st, const Relay relay = Relay { nullptr, nullptr, 0u, 0u } ) {
     constexpr int NST          = BOOL_ONLY ? MRT_STACK_LDS_BOOL : MRT_STACK_LDS;
     constexpr uint32_t LDS_TOP = MRT_XF_LDS * 12, LDS_STACK = LDS_TOP + MRT_TOP_LDS * 8, LDS_OUT = LDS_STACK + NST * MRT_TRACE_BLOCK * 2, LDS_PL = LDS_OUT + MRT_TRACE_BLOCK * 3;
     const lds_f32* xf_lds = (const lds_f32*)lds;
@@ -381,7 +467,15 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
 #ifdef MRT_EXTRA_VALU
     float extra_valu = 1.f; // measurement aid: MRT_EXTRA_VALU more vector-ALU instructions per trip
 #endif
+#ifdef MRT_TRIP_HISTOGRAM
+    uint32_t trips = 0;
+#endif
+    uint32_t tail_trips = 0; // trips since this wave found the list exhausted (wave-uniform)
     for ( ;; ) {
+        if ( !more ) tail_trips++;
+#ifdef MRT_TRIP_HISTOGRAM
+        trips++;
+#endif
 #ifdef MRT_EXTRA_VALU
 #pragma unroll
         for ( int i = 0; i < MRT_EXTRA_VALU; i++ )
@@ -409,6 +503,9 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 if ( rank < take && idx < n ) {
                     float ray_tmin, ray_tmax;
                     io.load( idx, tag, o, d, ray_tmin, ray_tmax );
+#ifdef MRT_TRIP_HISTOGRAM
+                    trips = 0;
+#endif
                     xr_id    = 0;
                     if ( !BOOL_ONLY ) {
                         v2f m;
@@ -416,35 +513,12 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                         *out_lds = m;
                     }
                     put_xr( o, d );
-                    // planes (kdtree.cpp:563-611): an any-hit ray stops at the first one accepted within
-                    // its interval; a closest-hit ray takes the nearest one, the first on ties (how far
-                    // it may lie is known when the ray retires)
-                    has_pl      = false;
-                    float btmax = ANY ? ray_tmax : __uint_as_float( 0x7f800000u );
-                    if ( STATS ) pl_tests = s.n_out;
-                    for ( uint32_t k = 0; k < s.n_out; k++ ) {
-                        const uint32_t po = s.out_of_tree[k];
-                        const uint32_t xf = __float_as_uint( ld_prim( s, po, 0 ).w ) >> MRT_PRIM_XF_SHIFT;
-                        V3 oo = o, od = d;
-                        if ( xf != 0 ) transform_ray( s, xf_lds, xf, o, d, oo, od );
-                        float t, u, v;
-                        if ( plane_test( oo, od, btmax, t, u, v ) ) {
-                            btmax = t; // accepted: later planes must be at least as near,
-                            // and replace this one only if strictly nearer
-                            bool better = true;
-                            if ( !BOOL_ONLY ) {
-                                if ( has_pl ) {
-                                    const v4f cur = *pl_lds;
-                                    better        = t < cur.y;
-                                }
-                                if ( better ) *pl_lds = mk4( __uint_as_float( po ), t, u, v );
-                            }
-                            has_pl = true;
-                            if ( ANY ) {
-                                if ( STATS ) pl_tests = k + 1;
-                                break;
-                            }
-                        }
+                    {
+                        v4f rec;
+                        uint32_t tested;
+                        has_pl = scan_planes<ANY>( s, xf_lds, o, d, ray_tmax, rec, tested );
+                        if ( STATS ) pl_tests = tested;
+                        if ( !BOOL_ONLY && has_pl ) *pl_lds = rec;
                     }
                     if ( ANY && BOOL_ONLY && has_pl ) {
                         DHit h;
@@ -583,7 +657,25 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         state = ( advance & !is_test ) ? MRT_ST_TEST : state;
         if ( pop ) {
             retire = sp == 0;
-            if ( sp != 0 ) {
+            bool handed_over = false;
+            if ( relay.list && tail_trips > relay.after && sp != 0 ) {
+                // a finite ray with no zero direction component: no split distance of it is NaN
+                const float lo = fminf( fminf( fabsf( d.x ), fabsf( d.y ) ), fabsf( d.z ) ), hi = fmaxf( fmaxf( fabsf( d.x ), fabsf( d.y ) ), fabsf( d.z ) );
+                const float om = fmaxf( fmaxf( fabsf( o.x ), fabsf( o.y ) ), fabsf( o.z ) );
+                if ( lo >= 1e-30f && hi < 1e30f && om < 1e30f && fabsf( b ) < 1e30f ) {
+                    const unsigned long long m = __ballot( true );
+                    const uint32_t rank        = __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0u ) );
+                    uint32_t base              = 0;
+                    if ( rank == 0 ) base = atomicAdd( relay.count, (uint32_t)__popcll( m ) );
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane( (int)base );
+                    if ( base + rank < relay.cap ) {
+                        relay.list[base + rank] = make_uint2( tag, __float_as_uint( b ) );
+                        handed_over             = true;
+                        state                   = MRT_ST_IDLE;
+                    }
+                }
+            }
+            if ( sp != 0 && !handed_over ) {
                 --sp;
                 v2u e;
                 if ( sp < NST ) e = stack_lds[sp * MRT_TRACE_BLOCK];
@@ -609,19 +701,13 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 h.u       = has ? rec.y : 0.f;
                 h.v       = has ? *outv_lds : 0.f;
                 h.outside = has ? __float_as_uint( rec.x ) >> 31 : 0u;
-                if ( has_pl ) {
-                    const v4f r = *pl_lds;
-                    // A closest-hit ray: the plane must lie within the tree hit distance or, without a
-                    // tree hit, within the tmax the ray came with (h.t in both cases), and replaces a
-                    // tree hit only if strictly nearer.  An any-hit ray: only without a tree hit.
-                    if ( ANY ? !has : ( has ? r.y < h.t : !( r.y > h.t ) ) ) {
-                        h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
-                        found  = true;
-                    }
-                }
+                if ( has_pl ) found = merge_plane<ANY>( has, h, true, *pl_lds );
             }
             io.store( tag, found, h );
             state = MRT_ST_IDLE;
+#ifdef MRT_TRIP_HISTOGRAM
+            atomicAdd( &g_trip_hist[31 - __clz( (int)( trips | 1u ) )], 1ull );
+#endif
         }
         // ---------------------------------------------------------------- issue
         if ( advance ) {
@@ -651,6 +737,107 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     }
 }
 
+// A hit as one 16-byte record: (prim | outside << 31 as bits, or 0xffffffff for a miss; t; u; v).
+MRT_DEV float4 pack_hit( const DHit& h ) {
+    const uint32_t bits = h.prim < 0 ? 0xffffffffu : ( (uint32_t)h.prim | ( h.outside ? 0x80000000u : 0u ) );
+    return make_float4( __uint_as_float( bits ), h.t, h.u, h.v );
+}
+MRT_DEV void unpack_hit( float4 r, DHit& h ) {
+    const uint32_t bits = __float_as_uint( r.x );
+    h.prim              = bits == 0xffffffffu ? -1 : (int32_t)( bits & 0x7fffffffu );
+    h.outside           = bits == 0xffffffffu ? 0u : bits >> 31;
+    h.t = r.y, h.u = r.z, h.v = r.w;
+}
+
+// The segments of the relayed rays as a ray list for trace_stream (see Relay): ray j is segment
+// j % MRT_RELAY_K of entry j / MRT_RELAY_K.  RAYS::reload( tag, o, d, tmax ) returns the ray an entry
+// names.  The interval that remains -- from the distance the entry carries to where the ray leaves
+// the root box or ends -- is cut at lo + (hi - lo) * k / K; neighbouring segments share their end
+// point, the first starts exactly at lo and the last ends exactly at hi.  The tree passed to the
+// kernel has no out-of-tree planes: they are the business of relay_finish_kernel.
+template <class RAYS, bool BOOL_ONLY>
+struct SegmentIO {
+    RAYS rays;
+    const uint2* list;
+    float root_min[3], root_max[3];
+    float4* hits;    // !BOOL_ONLY: one hit record per segment
+    uint32_t* flags; // BOOL_ONLY: one word per entry, zero before the launch, set when a segment found something
+    MRT_DEV void load( uint32_t j, uint32_t& tag, V3& o, V3& d, float& t0, float& t1 ) const {
+        tag            = j;
+        const uint2 e  = list[j / MRT_RELAY_K];
+        const uint32_t k = j % MRT_RELAY_K;
+        float hi;
+        rays.reload( e.x, o, d, hi );
+        float lo = __uint_as_float( e.y );
+        (void)clip_box( root_min, root_max, o, d, lo, hi );
+        const float w = hi - lo;
+        t0 = k == 0u ? lo : fminf( lo + w * ( (float)k * ( 1.f / MRT_RELAY_K ) ), hi );
+        t1 = k + 1u == MRT_RELAY_K ? hi : fminf( lo + w * ( (float)( k + 1u ) * ( 1.f / MRT_RELAY_K ) ), hi );
+    }
+    MRT_DEV void store( uint32_t j, bool found, const DHit& h ) const {
+        if ( BOOL_ONLY ) {
+            if ( found ) flags[j / MRT_RELAY_K] = 1u;
+        }
+        else {
+            DHit r = h;
+            if ( !found ) r.prim = -1;
+            hits[j] = pack_hit( r );
+        }
+    }
+};
+
+template <bool ANY, bool BOOL_ONLY, class RAYS>
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) relay_trace_kernel( DTrace tr, SegmentIO<RAYS, BOOL_ONLY> io, const uint32_t* __restrict__ count, uint32_t cap, uint32_t* __restrict__ deal ) {
+    __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( BOOL_ONLY )];
+    lds_u32* lp = (lds_u32*)lds;
+    const uint32_t n = *count < cap ? *count : cap;
+    DStats st { 0, 0, 0, 0 };
+    trace_stream<ANY, BOOL_ONLY, false>( tr, lp, io, n * MRT_RELAY_K, deal, st );
+}
+
+// Completes the relayed rays: the first segment that found something is the ray's tree result, the
+// planes are merged as at any retirement, and the ray's own IO stores the outcome.  IO::reload as in
+// SegmentIO.
+template <bool ANY, bool BOOL_ONLY, class IO>
+__global__ void __launch_bounds__( 256 ) relay_finish_kernel( DTrace tr, IO io, Relay relay, const float4* __restrict__ hits, uint32_t* __restrict__ flags, unsigned long long* __restrict__ total ) {
+    __shared__ uint32_t lds[MRT_XF_LDS * 12];
+    lds_u32* lp = (lds_u32*)lds;
+    stage_transforms( tr, (lds_f32*)lp );
+    const uint32_t n = *relay.count < relay.cap ? *relay.count : relay.cap;
+    if ( blockIdx.x == 0 && threadIdx.x == 0 && n != 0u ) atomicAdd( total, (unsigned long long)n ); // diagnostics: rays relayed on this handle so far
+    for ( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x ) {
+        const uint2 e = relay.list[i];
+        V3 o, d;
+        float far;
+        io.reload( e.x, o, d, far );
+        DHit h;
+        h.prim = -1, h.t = far, h.u = h.v = 0.f, h.outside = 0;
+        bool has = false;
+        if ( BOOL_ONLY ) {
+            has      = flags[i] != 0u;
+            flags[i] = 0u; // zero again for the next launch that uses the buffer
+            h.prim   = has ? 0 : -1;
+        }
+        else {
+            for ( uint32_t k = 0; k < MRT_RELAY_K && !has; k++ ) {
+                const float4 r = hits[(size_t)i * MRT_RELAY_K + k];
+                if ( __float_as_uint( r.x ) != 0xffffffffu ) {
+                    unpack_hit( r, h );
+                    has = true;
+                }
+            }
+        }
+        bool found = has;
+        if ( !BOOL_ONLY && tr.n_out != 0u ) {
+            v4f rec;
+            uint32_t tested;
+            const bool has_pl = scan_planes<ANY>( tr, (const lds_f32*)lp, o, d, far, rec, tested );
+            found             = merge_plane<ANY>( has, h, has_pl, rec );
+        }
+        io.store( e.x, found, h );
+    }
+}
+
 // Adds the lanes' counters to stats[0..3]: one atomic per wave and counter.
 MRT_DEV void flush_stats( const DStats& st, unsigned long long* stats ) {
     unsigned long long vals[4] = { st.inner, st.leaves, st.refs, st.tests };
@@ -668,15 +855,26 @@ MRT_DEV void flush_stats( const DStats& st, unsigned long long* stats ) {
 // when the list is short.
 template <class Kernel>
 inline uint32_t trace_grid_blocks( Kernel kernel, uint64_t n, int n_cus ) {
-    static int per_cu = 0; // one per kernel instantiation
-    if ( per_cu == 0 ) {
-        int v = 0;
-        if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &v, kernel, MRT_TRACE_BLOCK, 0 ) != hipSuccess || v < 1 ) v = 1;
-        if ( const char* e = std::getenv( "MRT_TRACE_BLOCKS_PER_CU" ) ) { // measurements: fewer resident blocks than fit
-            const int want = std::atoi( e );
-            if ( want >= 1 && want < v ) v = want;
+    // resident blocks per CU of this kernel instantiation on each device (0 = not asked yet); several
+    // host threads may render on several devices at once
+    static std::mutex mu;
+    static int per_cu_of[64] = {};
+    int dev = 0;
+    (void)hipGetDevice( &dev );
+    int per_cu = 0;
+    {
+        std::lock_guard<std::mutex> lock( mu );
+        int& slot = per_cu_of[dev >= 0 && dev < 64 ? dev : 0];
+        if ( slot == 0 ) {
+            int v = 0;
+            if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &v, kernel, MRT_TRACE_BLOCK, 0 ) != hipSuccess || v < 1 ) v = 1;
+            if ( const char* e = std::getenv( "MRT_TRACE_BLOCKS_PER_CU" ) ) { // measurements: fewer resident blocks than fit
+                const int want = std::atoi( e );
+                if ( want >= 1 && want < v ) v = want;
+            }
+            slot = v;
         }
-        per_cu = v;
+        per_cu = slot;
     }
     const uint64_t full = (uint64_t)n_cus * (uint64_t)per_cu;
     const uint64_t want = ( n + MRT_TRACE_BLOCK - 1 ) / MRT_TRACE_BLOCK;

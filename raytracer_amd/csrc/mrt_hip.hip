@@ -106,6 +106,19 @@ void parallel_ranges( size_t n, const Body& body ) {
 // ------------------------------------------------------------------------------------------------
 // scene
 // ------------------------------------------------------------------------------------------------
+// Buffers of one relay (device_trace.hpp: Relay): the list of handed-over rays, one hit record per
+// segment (traversals that report a hit) or one flag per ray (traversals that only answer "occluded").
+#define MRT_RELAY_CAP ( 1u << 17 )
+#define MRT_RELAY_AFTER_DEFAULT 256u
+// mrt_intersect's per-scene scratch: 8 x u64 traversal counters, MRT_DEAL_WORDS chunk counters, the relay's
+// counter (MRT_DEAL_STRIDE words apart from what follows), the relay launch's chunk counters
+#define MRT_INTERSECT_SCRATCH_BYTES ( 8 * sizeof( uint64_t ) + ( 2 * MRT_DEAL_WORDS + MRT_DEAL_STRIDE ) * sizeof( uint32_t ) )
+struct RelaySlot {
+    DevBuf<uint2> list;
+    DevBuf<float4> hits;
+    DevBuf<uint32_t> flags;
+};
+
 struct mrt_scene {
     int device = 0;
     DevBuf<uint4> nodes;
@@ -136,7 +149,13 @@ struct mrt_scene {
     // join them to the caller's stream
     hipStream_t side[2] = { nullptr, nullptr };
     hipEvent_t fork = nullptr, join[2] = { nullptr, nullptr };
-    uint64_t* d_stats = nullptr; // mrt_intersect: 8 x u64 traversal counters, then the MRT_DEAL_WORDS chunk counters
+    uint64_t* d_stats = nullptr; // mrt_intersect: 8 x u64 traversal counters, the MRT_DEAL_WORDS chunk counters, then the relay's counter and chunk counters
+    // relay of long rays (device_trace.hpp: Relay): one set of buffers per traversal launch that can be
+    // in flight at a time -- [0] continuation rays and mrt_intersect, [1] shadow rays, [2] MIS rays
+    RelaySlot relay[3];
+    uint64_t* d_relayed = nullptr; // rays relayed on this handle so far (mrt_debug_relayed)
+    uint32_t relay_after = MRT_RELAY_AFTER_DEFAULT;
+    bool relay_on        = true;
     uint32_t tree_depth = 0;
     int n_cus           = 256;
     bool no_emitters    = false; // no object has a material with a non-zero emission component
@@ -346,6 +365,7 @@ mrt_status scratch_for_device( int device, uint32_t** out ); // with mrt_interse
 }
 mrt_scene::~mrt_scene() {
     if ( d_stats ) (void)hipFree( d_stats );
+    if ( d_relayed ) (void)hipFree( d_relayed );
     if ( order ) (void)hipEventDestroy( order );
     if ( fork ) (void)hipEventDestroy( fork );
     for ( int k = 0; k < 2; k++ ) {
@@ -361,7 +381,7 @@ const char* mrt_last_error( void ) {
     return g_err.c_str();
 }
 int32_t mrt_version( void ) {
-    return 1;
+    return MRT_VERSION;
 }
 
 static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene** out );
@@ -557,7 +577,25 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
     HIP_TRY( s->xforms.upload( xforms ) );
     HIP_TRY( s->out_of_tree.upload( d->out_of_tree, d->n_out_of_tree ) );
     HIP_TRY( s->object_of.upload( object_of ) );
-    HIP_TRY( hipMalloc( (void**)&s->d_stats, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ) ) );
+    HIP_TRY( hipMalloc( (void**)&s->d_stats, MRT_INTERSECT_SCRATCH_BYTES ) );
+    HIP_TRY( hipMalloc( (void**)&s->d_relayed, sizeof( uint64_t ) ) );
+    HIP_TRY( hipMemset( s->d_relayed, 0, sizeof( uint64_t ) ) );
+    {
+        // MRT_RELAY=0 switches the relay of long rays off, MRT_RELAY_AFTER=<trips> sets how long a wave
+        // goes on after its list ran out before it hands its rays over (measurements and tests)
+        const char* e = std::getenv( "MRT_RELAY" );
+        s->relay_on   = !( e && std::strcmp( e, "0" ) == 0 );
+        if ( const char* a = std::getenv( "MRT_RELAY_AFTER" ) ) s->relay_after = (uint32_t)std::strtoul( a, nullptr, 10 );
+        if ( s->relay_on )
+            for ( int k = 0; k < 3; k++ ) {
+                HIP_TRY( s->relay[k].list.alloc( MRT_RELAY_CAP ) );
+                // the flags start at zero and every launch that used them leaves them at zero
+                HIP_TRY( s->relay[k].flags.alloc( MRT_RELAY_CAP ) );
+                HIP_TRY( hipMemset( s->relay[k].flags.p, 0, MRT_RELAY_CAP * sizeof( uint32_t ) ) );
+                // hit records: continuation rays and mrt_intersect; MIS rays only where they report hits
+                if ( k == 0 || ( k == 2 && !no_emitters ) ) HIP_TRY( s->relay[k].hits.alloc( (size_t)MRT_RELAY_CAP * MRT_RELAY_K ) );
+            }
+    }
     HIP_TRY( hipEventCreateWithFlags( &s->order, hipEventDisableTiming ) );
     HIP_TRY( hipEventRecord( s->order, 0 ) );
     HIP_TRY( hipEventCreateWithFlags( &s->fork, hipEventDisableTiming ) );
@@ -606,6 +644,14 @@ mrt_status mrt_scene_device_info( const mrt_scene* scene, mrt_device_info* out )
     return MRT_OK;
 }
 
+mrt_status mrt_debug_relayed( mrt_scene* scene, uint64_t* out ) {
+    if ( !scene || !out ) return fail( MRT_ERR_INVALID, "NULL argument" );
+    HIP_TRY( hipSetDevice( scene->device ) );
+    HIP_TRY( hipDeviceSynchronize() );
+    HIP_TRY( hipMemcpy( out, scene->d_relayed, sizeof( uint64_t ), hipMemcpyDeviceToHost ) );
+    return MRT_OK;
+}
+
 void mrt_scene_destroy( mrt_scene* scene ) {
     if ( !scene ) return;
     (void)hipSetDevice( scene->device );
@@ -635,15 +681,51 @@ struct BatchIO {
         u[i]    = h.u;
         v[i]    = h.v;
     }
+    MRT_DEV void reload( uint32_t i, V3& o, V3& d, float& t1 ) const {
+        o  = mk3( ox[i], oy[i], oz[i] );
+        d  = mk3( dx[i], dy[i], dz[i] );
+        t1 = tmax[i];
+    }
+    struct Rays {
+        const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax;
+        MRT_DEV void reload( uint32_t i, V3& o, V3& d, float& t1 ) const {
+            o  = mk3( ox[i], oy[i], oz[i] );
+            d  = mk3( dx[i], dy[i], dz[i] );
+            t1 = tmax[i];
+        }
+    };
+    Rays rays() const { return Rays { ox, oy, oz, dx, dy, dz, tmax }; }
 };
 
 template <bool ANY, bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) trace_batch_kernel( DTrace s, BatchIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) trace_batch_kernel( DTrace s, BatchIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
-    trace_stream<ANY, false, STATS>( s, lp, io, n, deal, st );
+    trace_stream<ANY, false, STATS>( s, lp, io, n, deal, st, relay );
     if ( STATS ) flush_stats( st, stats );
+}
+
+// The follow-up launches of a traversal launch that ran with the relay `r` (device_trace.hpp: Relay)
+// on `stream`: the segments of the handed-over rays, then their completion through the launch's own
+// IO.  `deal`: MRT_DEAL_WORDS chunk counters, zero.  Both kernels read the number of entries from the
+// device and end at once when there is none.
+template <bool ANY, bool BOOL_ONLY, class IO>
+static void launch_relay( const mrt_scene* sc, hipStream_t stream, const IO& io, const Relay& r, const RelaySlot& slot, uint32_t* deal ) {
+    if ( !r.list ) return;
+    typedef decltype( io.rays() ) RAYS;
+    DTrace tr = sc->trace;
+    tr.n_out  = 0; // the planes are merged by relay_finish_kernel
+    SegmentIO<RAYS, BOOL_ONLY> sio;
+    sio.rays  = io.rays();
+    sio.list  = r.list;
+    sio.hits  = slot.hits.p;
+    sio.flags = slot.flags.p;
+    for ( int k = 0; k < 3; k++ )
+        sio.root_min[k] = tr.root_min[k], sio.root_max[k] = tr.root_max[k];
+    auto kernel = relay_trace_kernel<ANY, BOOL_ONLY, RAYS>;
+    hipLaunchKernelGGL( kernel, dim3( trace_grid_blocks( kernel, (uint64_t)r.cap * MRT_RELAY_K, sc->n_cus ) ), dim3( MRT_TRACE_BLOCK ), 0, stream, tr, sio, r.count, r.cap, deal );
+    hipLaunchKernelGGL( ( relay_finish_kernel<ANY, BOOL_ONLY, IO> ), dim3( ( r.cap + 255u ) / 256u ), dim3( 256 ), 0, stream, sc->trace, io, r, slot.hits.p, slot.flags.p, (unsigned long long*)sc->d_relayed );
 }
 
 extern "C" mrt_status mrt_intersect( mrt_scene* sc,
@@ -696,19 +778,26 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
         dv    = hits->v;
     }
     HIP_TRY( hipStreamWaitEvent( stream, sc->order, 0 ) );
-    HIP_TRY( hipMemsetAsync( sc->d_stats, 0, 8 * sizeof( uint64_t ) + MRT_DEAL_WORDS * sizeof( uint32_t ), stream ) );
+    HIP_TRY( hipMemsetAsync( sc->d_stats, 0, MRT_INTERSECT_SCRATCH_BYTES, stream ) );
     const dim3 block( MRT_TRACE_BLOCK );
     unsigned long long* ds = (unsigned long long*)sc->d_stats;
+    uint32_t* const words  = (uint32_t*)( sc->d_stats + 8 ); // deal counters, relay counter (+ padding), the relay's deal counters
     const BatchIO io { din[0], din[1], din[2], din[3], din[4], din[5], din[6], din[7], dprim, dt, du, dv, sc->object_of.p };
+    // Long rays are relayed unless the visits are being counted (the counters are those of the plain
+    // traversal) and, for any-hit rays, unless the scene has emissive objects (see Relay).
+    Relay relay { nullptr, nullptr, 0u, 0u };
+    if ( sc->relay_on && !stats && ( flags == MRT_CLOSEST_HIT || sc->no_emitters ) ) relay = Relay { sc->relay[0].list.p, words + MRT_DEAL_WORDS, MRT_RELAY_CAP, sc->relay_after };
 #define LAUNCH( A, S ) \
-    hipLaunchKernelGGL( ( trace_batch_kernel<A, S> ), dim3( trace_grid_blocks( trace_batch_kernel<A, S>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, (uint32_t*)( sc->d_stats + 8 ), ds )
+    hipLaunchKernelGGL( ( trace_batch_kernel<A, S> ), dim3( trace_grid_blocks( trace_batch_kernel<A, S>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, words, ds, relay )
     if ( flags == MRT_ANY_HIT ) {
         if ( stats ) LAUNCH( true, true );
         else LAUNCH( true, false );
+        launch_relay<true, false>( sc, stream, io, relay, sc->relay[0], words + MRT_DEAL_WORDS + MRT_DEAL_STRIDE );
     }
     else {
         if ( stats ) LAUNCH( false, true );
         else LAUNCH( false, false );
+        launch_relay<false, false>( sc, stream, io, relay, sc->relay[0], words + MRT_DEAL_WORDS + MRT_DEAL_STRIDE );
     }
 #undef LAUNCH
     HIP_TRY( hipGetLastError() );
@@ -785,11 +874,24 @@ extern "C" mrt_status mrt_intersect_noalloc( mrt_scene* sc, uint64_t n, const mr
     const BatchIO io { in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], hits->prim, hits->t, hits->u, hits->v, sc->object_of.p };
     const dim3 block( MRT_TRACE_BLOCK );
     if ( flags == MRT_ANY_HIT )
-        hipLaunchKernelGGL( ( trace_batch_kernel<true, false> ), dim3( trace_grid_blocks( trace_batch_kernel<true, false>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, sp + 16, (unsigned long long*)sp );
+        hipLaunchKernelGGL( ( trace_batch_kernel<true, false> ), dim3( trace_grid_blocks( trace_batch_kernel<true, false>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, sp + 16, (unsigned long long*)sp, Relay { nullptr, nullptr, 0u, 0u } );
     else
-        hipLaunchKernelGGL( ( trace_batch_kernel<false, false> ), dim3( trace_grid_blocks( trace_batch_kernel<false, false>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, sp + 16, (unsigned long long*)sp );
+        hipLaunchKernelGGL( ( trace_batch_kernel<false, false> ), dim3( trace_grid_blocks( trace_batch_kernel<false, false>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, sp + 16, (unsigned long long*)sp, Relay { nullptr, nullptr, 0u, 0u } );
     HIP_TRY( hipGetLastError() );
     return MRT_OK;
 }
 
 #include "render_host.inc"
+
+#ifdef MRT_TRIP_HISTOGRAM
+// measurement aid (variant builds only): copies out, and optionally clears, the histogram of trips per ray
+extern "C" mrt_status mrt_debug_trip_histogram( unsigned long long* out32, int clear ) {
+    HIP_TRY( hipDeviceSynchronize() );
+    HIP_TRY( hipMemcpyFromSymbol( out32, HIP_SYMBOL( g_trip_hist ), 32 * sizeof( unsigned long long ) ) );
+    if ( clear ) {
+        unsigned long long zero[32] = {};
+        HIP_TRY( hipMemcpyToSymbol( HIP_SYMBOL( g_trip_hist ), zero, sizeof( zero ) ) );
+    }
+    return MRT_OK;
+}
+#endif

@@ -350,6 +350,13 @@ class DeviceScene:
             raise MrtError("mrt_intersect: %d %s" % (st, lib.mrt_last_error().decode()))
         return (prim, t, u, v, ts) if stats else (prim, t, u, v)
 
+    def relayed(self):
+        """mrt_debug_relayed: rays this handle's traversal launches have handed over so far."""
+        n = C.c_uint64()
+        if abi.hip().mrt_debug_relayed(self._h, C.byref(n)) != abi.MRT_OK:
+            raise MrtError(abi.hip().mrt_last_error().decode())
+        return n.value
+
     def debug_eval(self, fn, rows, out_width):
         """mrt_debug_eval: one device shading function on rows of floats (diagnostics)."""
         rows = np.ascontiguousarray(rows, np.float32)

@@ -182,7 +182,7 @@ def test_hip_library_exports_every_declared_symbol(built):
     lib = abi.hip()
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.mrt_version() == 1
+    assert lib.mrt_version() == 2
     hdr = open(os.path.join(ROOT, "include", "mrt_host_c.h")).read()
     hlib = abi.host()
     host_names = set(re.findall(r"^[a-z_0-9 \*]+?\b(mrth_[a-z_]+)\s*\(", hdr, re.M))
