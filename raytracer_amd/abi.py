@@ -140,8 +140,9 @@ def hip():
         lib.mrt_render_multi.restype = C.c_int32
         lib.mrt_debug_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32]
         lib.mrt_debug_eval.restype = C.c_int32
-        lib.mrt_debug_relayed.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-        lib.mrt_debug_relayed.restype = C.c_int32
+        if hasattr(lib, "mrt_debug_relayed"):  # (absent from builds of earlier revisions that tools/ab*.sh compare with)
+            lib.mrt_debug_relayed.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            lib.mrt_debug_relayed.restype = C.c_int32
         _hip = lib
     return _hip
 

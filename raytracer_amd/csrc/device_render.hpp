@@ -192,6 +192,7 @@ MRT_DEV void queue_push3( uint32_t* const* queue, uint32_t* counters, const bool
 // ------------------------------------------------------------------------------------------------
 // extend: closest hit of the continuation rays.  `queue` == nullptr means the identity queue.
 struct ExtendIO {
+    static constexpr bool is_segment_io = false;
     PathState ps;
     const uint32_t* queue;
     MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
@@ -211,6 +212,7 @@ struct ExtendIO {
 // Throughput 1, radiance 0, no pending term and the start of the engine stream are what the first
 // shade of a path assumes without reading them.
 struct CameraIO {
+    static constexpr bool is_segment_io = false;
     PathState ps;
     PassInfo pi;
     DCamera cam;
@@ -521,6 +523,7 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
 // ------------------------------------------------------------------------------------------------
 // connect_shadow: any-hit traversal of the shadow rays.
 struct ShadowIO {
+    static constexpr bool is_segment_io = false;
     PathState ps;
     const uint32_t* queue;
     MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
@@ -549,6 +552,7 @@ __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_sh
 // (shade has consumed the continuation hit by now and the next extend has not run yet);
 // mis_resolve_kernel turns it into the bsdf-sampling term.
 struct MisIO {
+    static constexpr bool is_segment_io = false;
     PathState ps;
     const uint32_t* queue;
     MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
@@ -577,6 +581,7 @@ __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mi
 // hit and in skipping emissive primitives, of which there are none).  So the ray is traced with
 // shadow-ray semantics: it stops at the first hit and a plane hit spares the tree altogether.
 struct MisOcclusionIO {
+    static constexpr bool is_segment_io = false;
     PathState ps;
     const uint32_t* queue;
     MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {

@@ -45,6 +45,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #ifndef MRT_STACK_MAX
 #define MRT_STACK_MAX 128 // deferred nodes per ray: trees up to depth 126 (the entries beyond the LDS part live in scratch)
@@ -398,11 +399,14 @@ MRT_DEV bool merge_plane( bool has, DHit& h, bool has_pl, v4f r ) {
 // follow one another along the ray, and the segments cut them at common points, so the first leaf with
 // an accepted hit, and the nearest accepted hit in it, are found by the first segment that reaches
 // into that leaf's part in front of and including the hit -- except where arithmetic on NaN decides (a
-// ray with a zero or non-finite component is never handed over) and for any-hit rays in a scene with
-// emissive objects, whose ignored hits shrink the interval for the rest of the leaf (the host does
-// not enable the relay for them).  list == nullptr: no relay.
+// ray with a zero or non-finite component is never handed over).  For an any-hit ray the same holds
+// for WHETHER it is occluded, provided the scene has no emissive object (ignored hits on those shrink
+// the interval for the rest of the leaf), but not for WHICH occluder it reports (the first accepted
+// in the leaf's list order, which a cut through the leaf changes): the host enables the relay for
+// any-hit launches only where they answer "occluded or not" in a scene without emissive objects.
+// list == nullptr: no relay.
 #ifndef MRT_RELAY_K
-#define MRT_RELAY_K 8u // segments per relayed ray (a power of two)
+#define MRT_RELAY_K 64u // segments per relayed ray (a power of two)
 #endif
 struct Relay {
     uint2* list;     // (tag, bits of the distance reached)
@@ -471,8 +475,13 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     uint32_t trips = 0;
 #endif
     uint32_t tail_trips = 0; // trips since this wave found the list exhausted (wave-uniform)
-    for ( ;; ) {
-        if ( !more ) tail_trips++;
+    const uint32_t relay_after = relay.list ? relay.after : 0xffffffffu;
+    // One trip of the wave's loop.  The loop exists twice: while the list may still have rays for this
+    // wave (TAIL false: with the refill, never ends by itself), and after that (TAIL true: without the
+    // refill, with the hand-over of long rays, returns false once every lane is idle).
+    auto trip = [&]( auto tail_c ) -> bool {
+        constexpr bool TAIL = decltype( tail_c )::value;
+        if ( TAIL ) tail_trips++;
 #ifdef MRT_TRIP_HISTOGRAM
         trips++;
 #endif
@@ -484,8 +493,8 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         // ---------------------------------------------------------------- refill
         const unsigned long long idle = __ballot( state == MRT_ST_IDLE );
         const uint32_t n_idle         = (uint32_t)__popcll( idle );
-        if ( !more && n_idle == 64u ) break;
-        if ( more && n_idle >= RefillMin<IO>::value ) {
+        if ( TAIL && n_idle == 64u ) return false;
+        if ( !TAIL && n_idle >= RefillMin<IO>::value ) {
             while ( left == 0 && part_try < 8u ) {
                 const uint32_t part = ( ( blockIdx.x & s.xcd_mask ) + part_try ) & 7u;
                 uint32_t got        = 0;
@@ -513,12 +522,34 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                         *out_lds = m;
                     }
                     put_xr( o, d );
-                    {
-                        v4f rec;
-                        uint32_t tested;
-                        has_pl = scan_planes<ANY>( s, xf_lds, o, d, ray_tmax, rec, tested );
-                        if ( STATS ) pl_tests = tested;
-                        if ( !BOOL_ONLY && has_pl ) *pl_lds = rec;
+                    // planes: the logic of scan_planes, written out here with the record kept in LDS (calling
+                    // the function, which keeps it in registers, made the whole frame 1.2 % slower)
+                    has_pl      = false;
+                    float btmax = ANY ? ray_tmax : __uint_as_float( 0x7f800000u );
+                    if ( STATS ) pl_tests = s.n_out;
+                    for ( uint32_t k = 0; k < s.n_out; k++ ) {
+                        const uint32_t po = s.out_of_tree[k];
+                        const uint32_t xf = __float_as_uint( ld_prim( s, po, 0 ).w ) >> MRT_PRIM_XF_SHIFT;
+                        V3 oo = o, od = d;
+                        if ( xf != 0 ) transform_ray( s, xf_lds, xf, o, d, oo, od );
+                        float t, u, v;
+                        if ( plane_test( oo, od, btmax, t, u, v ) ) {
+                            btmax = t; // accepted: later planes must be at least as near,
+                            // and replace this one only if strictly nearer
+                            bool better = true;
+                            if ( !BOOL_ONLY ) {
+                                if ( has_pl ) {
+                                    const v4f cur = *pl_lds;
+                                    better        = t < cur.y;
+                                }
+                                if ( better ) *pl_lds = mk4( __uint_as_float( po ), t, u, v );
+                            }
+                            has_pl = true;
+                            if ( ANY ) {
+                                if ( STATS ) pl_tests = k + 1;
+                                break;
+                            }
+                        }
                     }
                     if ( ANY && BOOL_ONLY && has_pl ) {
                         DHit h;
@@ -655,27 +686,28 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             pop                  = !retire & leaf_done;
         }
         state = ( advance & !is_test ) ? MRT_ST_TEST : state;
-        if ( pop ) {
-            retire = sp == 0;
-            bool handed_over = false;
-            if ( relay.list && tail_trips > relay.after && sp != 0 ) {
-                // a finite ray with no zero direction component: no split distance of it is NaN
-                const float lo = fminf( fminf( fabsf( d.x ), fabsf( d.y ) ), fabsf( d.z ) ), hi = fmaxf( fmaxf( fabsf( d.x ), fabsf( d.y ) ), fabsf( d.z ) );
-                const float om = fmaxf( fmaxf( fabsf( o.x ), fabsf( o.y ) ), fabsf( o.z ) );
-                if ( lo >= 1e-30f && hi < 1e30f && om < 1e30f && fabsf( b ) < 1e30f ) {
-                    const unsigned long long m = __ballot( true );
-                    const uint32_t rank        = __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0u ) );
-                    uint32_t base              = 0;
-                    if ( rank == 0 ) base = atomicAdd( relay.count, (uint32_t)__popcll( m ) );
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane( (int)base );
-                    if ( base + rank < relay.cap ) {
-                        relay.list[base + rank] = make_uint2( tag, __float_as_uint( b ) );
-                        handed_over             = true;
-                        state                   = MRT_ST_IDLE;
-                    }
+        if ( TAIL && tail_trips > relay_after ) {
+            // (wave-uniform branch, taken only in the tail of the launch) hand over the rays that have
+            // just finished a leaf without a hit and have deferred nodes left: finite rays with no zero
+            // direction component, none of whose split distances can be NaN
+            const float lo = fminf( fminf( fabsf( d.x ), fabsf( d.y ) ), fabsf( d.z ) ), hi = fmaxf( fmaxf( fabsf( d.x ), fabsf( d.y ) ), fabsf( d.z ) );
+            const float om = fmaxf( fmaxf( fabsf( o.x ), fabsf( o.y ) ), fabsf( o.z ) );
+            if ( pop && sp != 0 && lo >= 1e-30f && hi < 1e30f && om < 1e30f && fabsf( b ) < 1e30f ) {
+                const unsigned long long m = __ballot( true );
+                const uint32_t rank        = __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0u ) );
+                uint32_t base              = 0;
+                if ( rank == 0 ) base = atomicAdd( relay.count, (uint32_t)__popcll( m ) );
+                base = (uint32_t)__builtin_amdgcn_readfirstlane( (int)base );
+                if ( base + rank < relay.cap ) {
+                    relay.list[base + rank] = make_uint2( tag, __float_as_uint( b ) );
+                    pop                     = false;
+                    state                   = MRT_ST_IDLE;
                 }
             }
-            if ( sp != 0 && !handed_over ) {
+        }
+        if ( pop ) {
+            retire = sp == 0;
+            if ( sp != 0 ) {
                 --sp;
                 v2u e;
                 if ( sp < NST ) e = stack_lds[sp * MRT_TRACE_BLOCK];
@@ -701,11 +733,20 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 h.u       = has ? rec.y : 0.f;
                 h.v       = has ? *outv_lds : 0.f;
                 h.outside = has ? __float_as_uint( rec.x ) >> 31 : 0u;
-                if ( has_pl ) found = merge_plane<ANY>( has, h, true, *pl_lds );
+                if ( has_pl ) {
+                    const v4f r = *pl_lds;
+                    if ( ANY ? !has : ( has ? r.y < h.t : !( r.y > h.t ) ) ) {
+                        h.prim = (int32_t)__float_as_uint( r.x ), h.t = r.y, h.u = r.z, h.v = r.w, h.outside = 1;
+                        found  = true;
+                    }
+                }
             }
             io.store( tag, found, h );
             state = MRT_ST_IDLE;
 #ifdef MRT_TRIP_HISTOGRAM
+#ifdef MRT_TRIP_HISTOGRAM_RELAY_ONLY
+            if ( IO::is_segment_io )
+#endif
             atomicAdd( &g_trip_hist[31 - __clz( (int)( trips | 1u ) )], 1ull );
 #endif
         }
@@ -734,7 +775,11 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 L1 = ld_node( s, node, 1 );
             }
         }
-    }
+        return true;
+    };
+    while ( more )
+        (void)trip( std::false_type {} );
+    while ( trip( std::true_type {} ) ) {}
 }
 
 // A hit as one 16-byte record: (prim | outside << 31 as bits, or 0xffffffff for a miss; t; u; v).
@@ -757,6 +802,7 @@ MRT_DEV void unpack_hit( float4 r, DHit& h ) {
 // kernel has no out-of-tree planes: they are the business of relay_finish_kernel.
 template <class RAYS, bool BOOL_ONLY>
 struct SegmentIO {
+    static constexpr bool is_segment_io = true;
     RAYS rays;
     const uint2* list;
     float root_min[3], root_max[3];

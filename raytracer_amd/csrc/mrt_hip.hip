@@ -664,6 +664,7 @@ void mrt_scene_destroy( mrt_scene* scene ) {
 // mrt_intersect
 // ------------------------------------------------------------------------------------------------
 struct BatchIO {
+    static constexpr bool is_segment_io = false;
     const float *ox, *oy, *oz, *dx, *dy, *dz, *tmin, *tmax;
     int32_t* prim;
     float *t, *u, *v;
@@ -783,16 +784,17 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
     unsigned long long* ds = (unsigned long long*)sc->d_stats;
     uint32_t* const words  = (uint32_t*)( sc->d_stats + 8 ); // deal counters, relay counter (+ padding), the relay's deal counters
     const BatchIO io { din[0], din[1], din[2], din[3], din[4], din[5], din[6], din[7], dprim, dt, du, dv, sc->object_of.p };
-    // Long rays are relayed unless the visits are being counted (the counters are those of the plain
-    // traversal) and, for any-hit rays, unless the scene has emissive objects (see Relay).
+    // Long closest-hit rays are relayed unless the visits are being counted (the counters are those of
+    // the plain traversal).  Any-hit rays are not: which occluder they report -- the first one accepted
+    // in a leaf's list order, not the nearest -- depends on the whole interval the ray has in that leaf
+    // (see Relay; the renderer's shadow rays only report "occluded" and are relayed).
     Relay relay { nullptr, nullptr, 0u, 0u };
-    if ( sc->relay_on && !stats && ( flags == MRT_CLOSEST_HIT || sc->no_emitters ) ) relay = Relay { sc->relay[0].list.p, words + MRT_DEAL_WORDS, MRT_RELAY_CAP, sc->relay_after };
+    if ( sc->relay_on && !stats && flags == MRT_CLOSEST_HIT ) relay = Relay { sc->relay[0].list.p, words + MRT_DEAL_WORDS, MRT_RELAY_CAP, sc->relay_after };
 #define LAUNCH( A, S ) \
     hipLaunchKernelGGL( ( trace_batch_kernel<A, S> ), dim3( trace_grid_blocks( trace_batch_kernel<A, S>, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, words, ds, relay )
     if ( flags == MRT_ANY_HIT ) {
         if ( stats ) LAUNCH( true, true );
         else LAUNCH( true, false );
-        launch_relay<true, false>( sc, stream, io, relay, sc->relay[0], words + MRT_DEAL_WORDS + MRT_DEAL_STRIDE );
     }
     else {
         if ( stats ) LAUNCH( false, true );
