@@ -14,8 +14,13 @@ reported as `secondary` in the same JSON line.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): sample split, no exchange while
 rendering, the radiance-sum images are added onto rank 0 with one RCCL reduce per frame.
-  weak   (the headline `value`): rank r renders sample indices [r*1024, (r+1)*1024) of a 32 x 32N grid;
-  strong (`strong_split`): the 1024 samples of the 32 x 32 grid are divided among the ranks.
+  strong (the headline `value`, "scaling": "strong"): the 1024 samples of the 32 x 32 grid of the SAME frame
+         are divided among the ranks (BASELINE configs[2]: "1080p 1024 spp, sample-split across 8 GPUs");
+         ms_per_step is then the measured time to 1024 spp at 1080p on N GPUs;
+  weak   (`weak_split`, a side figure): rank r renders sample indices [r*1024, (r+1)*1024) of a 32 x 32N grid.
+At N = 1 the line also carries `strong_proxy`: what ONE GPU of a 2-, 4- and 8-way strong split has to do
+(samples [0, 1024/N) of the same grid) timed like the headline, and efficiency(N) = t(1024 spp) /
+(N * t(1024/N spp)) -- the scaling a node can reach before the reduce, measurable without the node.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline      the traversal kernel with the most device time: algorithmic bytes / HIP-event time
@@ -40,14 +45,14 @@ HBM_PEAK_GBS = 8000.0
 WORKLOADS = {
     "million_bunny": {
         "spp": (32, 32), "cpu_spp": 64, "mis_kernel": "connect_mis_occlusion_kernel",  # no emitter besides the environment
-        "label": "stanford bunny subdivided twice (1 111 216 triangles), glossy, plane floor, HDR env, 1920x1080, %d spp per GPU, "
+        "label": "stanford bunny subdivided twice (1 111 216 triangles), glossy, plane floor, HDR env, 1920x1080, %d spp, "
                  "max depth 5 (BASELINE configs[2] class; dragon.obj is not distributed)",
         "data": "stanford-bunny.obj (69 451 triangles, 1->4 subdivided twice, vertices x80) + brown_photostudio_06_1k.hdr committed "
                 "under assets/; camera, material and floor synthetic",
     },
     "bunny_pair": {
         "spp": (16, 16), "cpu_spp": 32, "mis_kernel": "connect_mis_occlusion_kernel",
-        "label": "stanford-bunny diffuse+glossy, 1920x1080, %d spp per GPU, max depth 5, HDR env (BASELINE configs[1])",
+        "label": "stanford-bunny diffuse+glossy, 1920x1080, %d spp, max depth 5, HDR env (BASELINE configs[1])",
         "data": "stanford-bunny.obj (69 451 triangles, x2 instances, vertices x20) + brown_photostudio_06_1k.hdr committed under "
                 "assets/; camera, materials and floor synthetic",
     },
@@ -69,25 +74,6 @@ def profile_traffic(workload, kernel):
         return w["bytes_per_launch"].get(kernel), w.get("tcc_hit_rate", {}).get(kernel)
     except Exception:
         return None, None
-
-
-def profile_gather_ceiling(workload, kernel):
-    """The kernel's L2 request rate against what a loop of nothing but dependent 32-byte gathers
-    reaches on this GPU at the kernel's occupancy and L2 hit rate (profiles/r02_gather_ceiling.json:
-    tools/micro/gather_bench.hip + the committed counter passes); None when not profiled."""
-    if workload != "million_bunny":
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_gather_ceiling.json")) as f:
-            g = json.load(f)
-        k = g["kernels"][kernel]
-        return {"l2_requests_G_per_s": k["g_requests_per_s"], "l2_hit_rate": k["l2_hit_rate"], "ceiling_G_per_s": k["ceiling_g_per_s"],
-                "frac": k["fraction"], "model": g["model"],
-                "source": "not measured in this run: the request rate and hit rate are from the committed counter passes of this workload "
-                          "(profiles/r02_million_bunny_mem_pipe.json, r02_million_bunny_pmc_summary.json), the gather rates from "
-                          "profiles/r02_gather_ceiling.txt (raytracer_amd/gather_bench)"}
-    except Exception:
-        return None
 
 
 def measure(name, args, rank, world, dist, local_rank, with_cpu):
@@ -151,14 +137,15 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
             return float(tmax[0]), float(tot[0]), float(tot[1]), kms, passes
         return elapsed, float(rays), float(paths), kms, passes
 
-    weak = parallel.rank_params(WIDTH, HEIGHT, spp_x, spp_y, rank, world, max_depth=MAX_DEPTH, seed=SEED, weak=True)
+    # the headline: the whole frame at N = 1, its strong (sample) split at N > 1
+    weak = parallel.rank_params(WIDTH, HEIGHT, spp_x, spp_y, rank, world, max_depth=MAX_DEPTH, seed=SEED, weak=(world == 1))
     for _ in range(args.warmup):
         timed(weak, 1)
     # one untimed pass with the traversal counters on (rank 0 only, no collective): the node / leaf /
     # reference / primitive-test visits the kernels really make, per ray class, for the roofline
     own = None
     if rank == 0 and with_cpu:
-        sp = render_params(WIDTH, HEIGHT, spp_x, spp_y * world, max_depth=MAX_DEPTH, seed=SEED, sample_begin=0,
+        sp = render_params(WIDTH, HEIGHT, spp_x, spp_y, max_depth=MAX_DEPTH, seed=SEED, sample_begin=0,
                            sample_end=min(spp, 256), flags=abi.MRT_RENDER_TRACE_STATS | abi.MRT_RENDER_SERIAL)
         sp.paths_per_pass = args.paths_per_pass
         scratch = torch.zeros_like(img)
@@ -179,17 +166,29 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
         del tmp
         kms = {"generate": rs.generate_ms * args.steps, "extend": rs.extend_ms * args.steps, "shade": rs.shade_ms * args.steps,
                "connect": rs.connect_ms * args.steps, "connect_mis": rs.connect_mis_ms * args.steps}
-    mean_radiance = float(img.mean().item()) / (spp * world) if rank == 0 else 0.0
+    mean_radiance = float(img.mean().item()) / spp if rank == 0 else 0.0
 
-    strong = None
+    side = None  # N > 1: the weak split beside the headline
     if world > 1:
-        sparams = parallel.rank_params(WIDTH, HEIGHT, spp_x, spp_y, rank, world, max_depth=MAX_DEPTH, seed=SEED, weak=False)
-        timed(sparams, 1)
-        s_elapsed, s_rays, s_paths, _, _ = timed(sparams, args.steps)
-        strong = {"value": s_rays / s_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": s_elapsed / args.steps * 1e3,
-                  "spp_per_gpu": spp / world, "scaling": "strong"}
-        if name == "million_bunny" and spp == 1024:
-            strong["seconds_to_1024spp_1080p"] = s_elapsed / args.steps
+        wparams = parallel.rank_params(WIDTH, HEIGHT, spp_x, spp_y, rank, world, max_depth=MAX_DEPTH, seed=SEED, weak=True)
+        timed(wparams, 1)
+        w_elapsed, w_rays, w_paths, _, _ = timed(wparams, args.steps)
+        side = {"value": w_rays / w_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": w_elapsed / args.steps * 1e3,
+                "spp_per_gpu": spp, "scaling": "weak"}
+
+    # N = 1: what one GPU of an N-way strong split has to do, timed like the headline
+    proxy = None
+    if world == 1 and not args.no_strong_proxy and spp % 8 == 0:
+        proxy = {"note": "samples [0, spp/N) of the same %d x %d grid on this one GPU; efficiency = t(spp) / (N * t(spp/N)): the "
+                         "strong-split scaling before the reduce (one RCCL reduce of a 24.9 MB image per frame)" % (spp_x, spp_y),
+                 "ms_full_frame": elapsed / args.steps * 1e3}
+        for n_way in (2, 4, 8):
+            pp = render_params(WIDTH, HEIGHT, spp_x, spp_y, max_depth=MAX_DEPTH, seed=SEED, sample_begin=0, sample_end=spp // n_way)
+            timed(pp, 1)
+            p_elapsed, _, _, _, _ = timed(pp, args.steps)
+            proxy["n%d" % n_way] = {"spp": spp // n_way, "ms": p_elapsed / args.steps * 1e3,
+                                    "efficiency": (elapsed / args.steps) / (n_way * p_elapsed / args.steps)}
+        proxy["efficiency"] = proxy["n8"]["efficiency"]
 
     if rank != 0:
         dev.close()
@@ -202,7 +201,7 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
         "data": wl["data"],
         "config": {
             "workload": wl["label"] % spp + ("" if (spp_x, spp_y) == wl["spp"] else " [reduced spp for profiling]"),
-            "width": WIDTH, "height": HEIGHT, "spp_per_gpu": spp, "max_depth": MAX_DEPTH,
+            "width": WIDTH, "height": HEIGHT, "spp_per_gpu": spp / world, "max_depth": MAX_DEPTH,
             "triangles": sc.n_objects - 1, "kd_nodes": n_nodes, "kd_refs": n_refs, "kd_depth": depth,
             "kd_build_s": round(build_s, 2),
             "parallelism": "sample-split x%d + RCCL reduce" % world if world > 1 else "single GPU",
@@ -215,14 +214,13 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
                           "overlap the shadow, MIS and next-bounce traversal launches, so their sum exceeds ms_per_step" if not args.serial
                           else "all frames rendered with MRT_RENDER_SERIAL (one kernel at a time)",
     }
-    if name == "million_bunny":
-        # measured, not extrapolated: one step of the N = 1 run IS 1024 spp at 1080p
-        if world == 1 and spp == 1024:
-            out["seconds_to_1024spp_1080p"] = elapsed / args.steps
-        elif strong and "seconds_to_1024spp_1080p" in strong:
-            out["seconds_to_1024spp_1080p"] = strong["seconds_to_1024spp_1080p"]
-    if strong:
-        out["strong_split"] = strong
+    if name == "million_bunny" and spp == 1024:
+        # measured, not extrapolated: one step IS 1024 spp at 1080p (on one GPU, or divided among the N ranks)
+        out["seconds_to_1024spp_1080p"] = elapsed / args.steps
+    if side:
+        out["weak_split"] = side
+    if proxy:
+        out["strong_proxy"] = proxy
 
     cpu = roof = None
     if with_cpu:
@@ -231,7 +229,7 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
         # for its workers, so the thread count is passed to the oracle explicitly)
         cores = min(os.cpu_count() or 1, 16)
         cpu_s = max(1, min((args.cpu_spp or wl["cpu_spp"]) if world == 1 else 1, spp))
-        cp = render_params(WIDTH, HEIGHT, spp_x, spp_y * world, max_depth=MAX_DEPTH, seed=SEED, sample_begin=0, sample_end=cpu_s)
+        cp = render_params(WIDTH, HEIGHT, spp_x, spp_y, max_depth=MAX_DEPTH, seed=SEED, sample_begin=0, sample_end=cpu_s)
         tc = time.perf_counter()
         cimg, crs, cts, _ = orc.oracle_render(flat.desc, cp, 0, threads=cores)
         cpu_t = time.perf_counter() - tc
@@ -283,9 +281,6 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
         if traffic and launches:
             roof["hbm_frac_from_counters"] = traffic / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof["limiter"] = "L2 / memory-side-cache gather latency (TCC hit rate %.2f)" % hit_rate if hit_rate else "L2 gather latency"
-        gc = profile_gather_ceiling(name, kname) if (spp_x, spp_y) == wl["spp"] and world == 1 else None
-        if gc:
-            roof["gather_ceiling"] = gc
     out["roofline"] = roof
     out["cpu_baseline"] = cpu
     dev.close()
@@ -300,6 +295,7 @@ def main():
     ap.add_argument("--workload", default="million_bunny", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and roofline legs")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] measurement")
+    ap.add_argument("--no-strong-proxy", action="store_true", help="skip the N = 1 strong-split proxy")
     ap.add_argument("--serial", action="store_true", help="render every frame with one kernel at a time (profiling runs: per-kernel "
                                                           "durations of a kernel trace are then each kernel's own)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU sample (0 = the workload's default)")
@@ -340,6 +336,7 @@ def main():
         other = "bunny_pair" if args.workload == "million_bunny" else "million_bunny"
         sargs = argparse.Namespace(**vars(args))
         sargs.cpu_spp = 0
+        sargs.no_strong_proxy = True
         secondary = measure(other, sargs, rank, world, dist, local_rank, with_cpu=not args.no_cpu)
     if rank == 0:
         result = {
@@ -351,7 +348,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": main_res.pop("ms_per_step"),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
         }
