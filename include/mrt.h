@@ -203,7 +203,7 @@ typedef struct mrt_render_params {
     uint32_t max_depth;                    /* Pathtracer(maxDepth, ...) */
     uint32_t seed;                         /* replaces time(NULL) of CPURenderer.cpp:42 */
     uint32_t row_begin, row_end;           /* scanlines rendered by this call (tile split) */
-    uint32_t paths_per_pass;               /* 0 = library default */
+    uint32_t paths_per_pass;               /* 0 = library default; at most 2^30 (MRT_ERR_UNSUPPORTED beyond) */
     uint32_t flags;                        /* MRT_RENDER_* */
 } mrt_render_params;
 
@@ -270,7 +270,9 @@ mrt_status mrt_intersect( mrt_scene* scene,
  * (its address on a device is looked up when the first mrt_scene is created there).  Every call on
  * one GPU, whatever the scene handle or stream, shares that GPU's array: calls that overlap in
  * time on one GPU race (rays are skipped or traced twice) -- order them on one stream or with
- * events.  n > MRT_NOALLOC_MAX_RAYS is rejected with MRT_ERR_UNSUPPORTED. */
+ * events.  Unlike the other calls it neither waits on nor records the handle's ordering event (it
+ * shares no per-handle scratch): it is ordered by `stream` alone, also against other calls on the
+ * same handle.  n > MRT_NOALLOC_MAX_RAYS is rejected with MRT_ERR_UNSUPPORTED. */
 #define MRT_NOALLOC_MAX_RAYS 0x7fffffffull
 #define MRT_NOALLOC_SCRATCH_BYTES 1088u
 mrt_status mrt_intersect_noalloc( mrt_scene* scene,
@@ -314,6 +316,20 @@ mrt_status mrt_resolve( mrt_scene* scene,
  * is keyed by (seed, pixel, sample index), so the frame equals the single-handle frame up to the
  * order of the fp32 additions of the per-handle sums. */
 mrt_status mrt_reduce( mrt_scene* const* scenes, float* const* images, int32_t n, uint64_t n_floats, int32_t root );
+/* mrt_reduce without waiting on the host, for a loop that reduces every few samples (progressive
+ * display): ordered after the calls made so far through the handles (mrt_render into images[i] on any
+ * stream) by their per-handle events, executed on `stream` (a hipStream_t of the root's device, NULL =
+ * its default stream), and later calls through any of the handles are ordered after it.  Images the
+ * caller wrote by other means must be complete on its own account.  The root handle keeps a staging
+ * image of n_floats until mrt_scene_trim or mrt_scene_destroy. */
+mrt_status mrt_reduce_async( mrt_scene* const* scenes, float* const* images, int32_t n, uint64_t n_floats, int32_t root, void* stream );
+
+/* Gives back the device memory a handle keeps between calls: the path-state workspace of mrt_render
+ * (by default a pass takes what the frame needs, up to 2^30 paths and up to 82 % of the memory that is
+ * free at the time -- and the workspace stays allocated for the next frame) and the staging image of
+ * mrt_reduce.  Waits for the handle's work; the next call allocates again.  No counterpart in the
+ * reference (its per-sample state lives on the C++ stack). */
+mrt_status mrt_scene_trim( mrt_scene* scene );
 mrt_status mrt_render_multi( mrt_scene* const* scenes, int32_t n, const mrt_render_params* params, float* rgb_sum_host, mrt_render_stats* stats );
 
 /* Diagnostics: evaluates ONE device function of the shading code on `n` rows of host floats

@@ -136,6 +136,11 @@ def hip():
         lib.mrt_scene_device_info.restype = C.c_int32
         lib.mrt_reduce.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.c_int32]
         lib.mrt_reduce.restype = C.c_int32
+        if hasattr(lib, "mrt_reduce_async"):
+            lib.mrt_reduce_async.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]
+            lib.mrt_reduce_async.restype = C.c_int32
+            lib.mrt_scene_trim.argtypes = [C.c_void_p]
+            lib.mrt_scene_trim.restype = C.c_int32
         lib.mrt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
         lib.mrt_render_multi.restype = C.c_int32
         lib.mrt_debug_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32]

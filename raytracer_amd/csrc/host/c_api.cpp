@@ -354,14 +354,16 @@ int mrth_save_png( const char* filename, const float* rgb, uint32_t w, uint32_t 
 // image_texture( filename ): the texels (byte / 255.f, [h][w][3]) into rgb when it holds
 // capacity_floats >= w * h * 3; w, h are always written.  -1 when the file cannot be decoded.
 int mrth_load_image( const char* filename, uint32_t* w, uint32_t* h, float* rgb, uint64_t capacity_floats ) {
-    std::unique_ptr<texture> t( image_texture( filename ) );
-    if ( !t ) {
-        g_err = std::string( "cannot decode " ) + filename;
-        return -1;
-    }
-    *w = t->width, *h = t->height;
-    if ( rgb && capacity_floats >= t->texels.size() ) std::memcpy( rgb, t->texels.data(), t->texels.size() * sizeof( float ) );
-    return 0;
+    return guarded( [&] {
+        std::unique_ptr<texture> t( image_texture( filename ) );
+        if ( !t ) {
+            g_err = std::string( "cannot decode " ) + filename;
+            return -1;
+        }
+        *w = t->width, *h = t->height;
+        if ( rgb && capacity_floats >= t->texels.size() ) std::memcpy( rgb, t->texels.data(), t->texels.size() * sizeof( float ) );
+        return 0;
+    } );
 }
 int mrth_material_set_image_file( void* scene_, int id, const char* filename, void* tex_xf ) {
     auto* scene = static_cast<Scene*>( scene_ );
@@ -369,15 +371,17 @@ int mrth_material_set_image_file( void* scene_, int id, const char* filename, vo
         g_err = "material id out of range";
         return -1;
     }
-    texture* t = image_texture( filename );
-    if ( !t ) {
-        g_err = std::string( "cannot decode " ) + filename;
-        return -1;
-    }
-    if ( tex_xf ) t->m_transform = *static_cast<Transform*>( tex_xf );
-    scene->owned_textures.push_back( t );
-    scene->GetMaterial( id ).m_texture = t;
-    return 0;
+    return guarded( [&] {
+        std::unique_ptr<texture> t( image_texture( filename ) );
+        if ( !t ) {
+            g_err = std::string( "cannot decode " ) + filename;
+            return -1;
+        }
+        if ( tex_xf ) t->m_transform = *static_cast<Transform*>( tex_xf );
+        scene->owned_textures.push_back( t.get() );
+        scene->GetMaterial( id ).m_texture = t.release();
+        return 0;
+    } );
 }
 
 int mrth_hip_render( void* scene, uint32_t w, uint32_t h, int spp_x, int spp_y, int max_depth, uint32_t seed, int device, float* rgb_sum, mrt_render_stats* stats, double* seconds ) {

@@ -84,6 +84,10 @@ struct Huffman {
     }
 };
 
+// the decoded stream may not grow beyond this (set by the caller from the picture's header: a file
+// cannot make the reader allocate more than its own header accounts for)
+thread_local size_t g_inflate_limit = ~(size_t)0;
+
 bool inflate_codes( BitReader& br, std::vector<unsigned char>& out, const Huffman& lit, const Huffman& dist ) {
     static const uint16_t lbase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
     static const uint16_t lext[29]  = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
@@ -92,7 +96,10 @@ bool inflate_codes( BitReader& br, std::vector<unsigned char>& out, const Huffma
     for ( ;; ) {
         int sym = lit.decode( br );
         if ( sym < 0 ) return false;
-        if ( sym < 256 ) out.push_back( (unsigned char)sym );
+        if ( sym < 256 ) {
+            if ( out.size() >= g_inflate_limit ) return false;
+            out.push_back( (unsigned char)sym );
+        }
         else if ( sym == 256 ) return true;
         else {
             sym -= 257;
@@ -101,7 +108,7 @@ bool inflate_codes( BitReader& br, std::vector<unsigned char>& out, const Huffma
             int ds     = dist.decode( br );
             if ( ds < 0 || ds >= 30 ) return false;
             size_t d = dbase[ds] + br.bits( dext[ds] );
-            if ( br.bad || d > out.size() ) return false;
+            if ( br.bad || d > out.size() || len > g_inflate_limit - out.size() ) return false;
             size_t from = out.size() - d;
             for ( size_t i = 0; i < len; i++ )
                 out.push_back( out[from + i] );
@@ -133,7 +140,7 @@ bool zlib_inflate( const unsigned char* z, size_t n, std::vector<unsigned char>&
             size_t byte  = br.pos >> 3;
             if ( byte + 4 > br.n ) return false;
             uint32_t len = br.p[byte] | ( br.p[byte + 1] << 8 ), nlen = br.p[byte + 2] | ( br.p[byte + 3] << 8 );
-            if ( ( len ^ 0xffffu ) != nlen || byte + 4 + len > br.n ) return false;
+            if ( ( len ^ 0xffffu ) != nlen || byte + 4 + len > br.n || len > g_inflate_limit - out.size() ) return false;
             out.insert( out.end(), br.p + byte + 4, br.p + byte + 4 + len );
             br.pos = ( byte + 4 + len ) << 3;
         }
@@ -255,12 +262,21 @@ bool decode_png_rgb8( const unsigned char* file, size_t size, uint32_t& w, uint3
     const bool depth_ok = ( ctype == 0 ) ? ( depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16 )
                                          : ( ctype == 3 ? ( depth == 1 || depth == 2 || depth == 4 || depth == 8 ) : ( depth == 8 || depth == 16 ) );
     if ( !depth_ok ) return false;
-    if ( (uint64_t)w * h > ( 1ull << 31 ) ) return false;
+    // a texture is at most 65535 x 65535 texels (the limit the device library applies as well)
+    if ( w == 0 || h == 0 || w >= ( 1u << 16 ) || h >= ( 1u << 16 ) ) return false;
     const size_t bits_pp = (size_t)channels * depth, bpp = ( bits_pp + 7 ) / 8;
 
+    // What the header promises, filter bytes included (an interlaced picture adds at most 15 bytes per
+    // row of each of its seven sub-images).  Deflate expands at most 1032 : 1, so a header that promises
+    // more than the file's compressed data can hold is wrong: nothing is allocated for it.
+    const size_t expected = ( ( (size_t)w * bits_pp + 7 ) / 8 + 1 ) * h + ( interlace ? (size_t)7 * 16 * ( (size_t)h + 8 ) : 0 );
+    if ( expected / 1032 > idat.size() + 1 ) return false;
     std::vector<unsigned char> raw;
-    raw.reserve( ( ( (size_t)w * bits_pp + 7 ) / 8 + 1 ) * h );
-    if ( !zlib_inflate( idat.data(), idat.size(), raw ) ) return false;
+    raw.reserve( expected );
+    g_inflate_limit = expected;
+    const bool inflated = zlib_inflate( idat.data(), idat.size(), raw );
+    g_inflate_limit     = ~(size_t)0;
+    if ( !inflated ) return false;
 
     rgb.assign( (size_t)w * h * 3, 0 );
     // one (sub-)image: its pixel (x, y) is pixel (x0 + x * dx, y0 + y * dy) of the picture

@@ -190,7 +190,16 @@ texture* checker_texture( color3 c1, color3 c2 ) {
 }
 // image_texture( filename ) (textures.hpp:50-62 -> loadPng, image.cpp:13-40): a PNG file, or a
 // binary PPM (P6, maxval 255) holding the same bytes.  The value mapping is loadPng's, byte / 255.f.
+static texture* image_texture_unguarded( const char* filename );
 texture* image_texture( const char* filename ) {
+    try { // a file that cannot be read for whatever reason, memory included, is "no texture", not an exception
+        return image_texture_unguarded( filename );
+    }
+    catch ( const std::exception& ) {
+        return nullptr;
+    }
+}
+static texture* image_texture_unguarded( const char* filename ) {
     FILE* f = std::fopen( filename, "rb" );
     if ( !f ) return nullptr;
     unsigned char sig[2] = { 0, 0 };
@@ -211,6 +220,15 @@ texture* image_texture( const char* filename ) {
         }
         std::fgetc( f );
         w = (uint32_t)pw, h = (uint32_t)ph;
+        // the header must not promise more than the file holds (nor more than a texture may have)
+        const long at = std::ftell( f );
+        std::fseek( f, 0, SEEK_END );
+        const long file_end = std::ftell( f );
+        if ( at < 0 || file_end < at || w >= ( 1u << 16 ) || h >= ( 1u << 16 ) || (uint64_t)w * h * 3 > (uint64_t)( file_end - at ) ) {
+            std::fclose( f );
+            return nullptr;
+        }
+        std::fseek( f, at, SEEK_SET );
         buf.resize( (size_t)w * h * 3 );
         size_t got = std::fread( buf.data(), 1, buf.size(), f );
         std::fclose( f );
@@ -336,7 +354,24 @@ struct ObjData {
 
 // What follows restates the OBJ / MTL reading of the reference's tiny_obj_loader.h (v1.0.6) statement
 // by statement: which faces exist, their order (it numbers the primitives) and every float depend on
-// its grammar and on its arithmetic, neither of which is strtod's.
+// its grammar and on its arithmetic, neither of which is strtod's.  tiny_obj_loader.h is third-party
+// code the reference vendors under the MIT licence; the number parser below (parse_double, parse_triple,
+// fix_index) follows its tryParseDouble / parseReal / fixIndex closely enough to carry its notice:
+//
+//   The MIT License (MIT)
+//   Copyright (c) 2012-2016 Syoyo Fujita and many contributors.
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and
+//   associated documentation files (the "Software"), to deal in the Software without restriction,
+//   including without limitation the rights to use, copy, modify, merge, publish, distribute,
+//   sublicense, and/or sell copies of the Software, and to permit persons to whom the Software is
+//   furnished to do so, subject to the following conditions:
+//   The above copyright notice and this permission notice shall be included in all copies or
+//   substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT
+//   NOT LIMITED TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND
+//   NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM,
+//   DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT
+//   OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
 
 inline bool is_space( char c ) {
     return c == ' ' || c == '\t';

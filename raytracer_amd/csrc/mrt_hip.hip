@@ -154,6 +154,7 @@ struct mrt_scene {
     // in flight at a time -- [0] continuation rays and mrt_intersect, [1] shadow rays, [2] MIS rays
     RelaySlot relay[3];
     uint64_t* d_relayed = nullptr; // rays relayed on this handle so far (mrt_debug_relayed)
+    DevBuf<float> reduce_staging;  // mrt_reduce: where the other handles' images land on this (the root's) device
     uint32_t relay_after = MRT_RELAY_AFTER_DEFAULT;
     bool relay_on        = true;
     uint32_t tree_depth = 0;

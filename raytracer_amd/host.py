@@ -350,6 +350,11 @@ class DeviceScene:
             raise MrtError("mrt_intersect: %d %s" % (st, lib.mrt_last_error().decode()))
         return (prim, t, u, v, ts) if stats else (prim, t, u, v)
 
+    def trim(self):
+        """mrt_scene_trim: gives back the workspace the handle keeps between calls."""
+        if abi.hip().mrt_scene_trim(self._h) != abi.MRT_OK:
+            raise MrtError(abi.hip().mrt_last_error().decode())
+
     def relayed(self):
         """mrt_debug_relayed: rays this handle's traversal launches have handed over so far."""
         n = C.c_uint64()

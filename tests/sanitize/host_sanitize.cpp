@@ -4,6 +4,7 @@
 // validation.  No GPU is touched: mrt_scene_create is expected to stop at "no device" or earlier.
 // usage: host_sanitize <assets directory>
 #include "host_math.hpp" // the host library's internal header: mrt_host.hpp + the PNG decoder
+#include "mrt_host_c.h"
 
 #include <cstdio>
 #include <fstream>
@@ -195,6 +196,30 @@ int main( int argc, char** argv ) {
                 bad[41 + ( state >> 8 ) % ( bad.size() - 41 )] ^= (unsigned char)( 1u << ( state & 7u ) );
             }
             decode_png_rgb8( bad.data(), bad.size(), w, h, rgb ); // either outcome
+        }
+        // headers that promise far more than the file holds: refused before anything is allocated for them
+        // (the IHDR checksum is not checked by the reader, so patching the fields is enough)
+        for ( const uint32_t dim : { 0x7fffffffu, 0x00ffffffu, 65536u, 46341u } ) {
+            std::vector<unsigned char> big = bytes;
+            for ( int k = 0; k < 4; k++ )
+                big[16 + k] = big[20 + k] = (unsigned char)( dim >> ( 24 - 8 * k ) ); // width, height
+            big[24] = 16, big[25] = 6; // 16 bits, RGBA: 64 bits per pixel
+            CHECK( !decode_png_rgb8( big.data(), big.size(), w, h, rgb ) );
+        }
+        {
+            // a 50-byte PPM whose header claims 2^31 - 1 by 2^31 - 1 pixels, and one within the size limit
+            // of a texture that still claims more than the file holds
+            for ( const char* header : { "P6 2147483647 2147483647 255\n", "P6 60000 60000 255\n", "P6 65536 1 255\n" } ) {
+                const std::string path = "/tmp/mrt_host_sanitize_big.ppm";
+                {
+                    std::ofstream o( path, std::ios::binary );
+                    o << header << "0123456789abcdefghij";
+                }
+                CHECK( image_texture( path.c_str() ) == nullptr );
+                uint32_t iw = 0, ih = 0;
+                CHECK( mrth_load_image( path.c_str(), &iw, &ih, nullptr, 0 ) == -1 );
+                std::remove( path.c_str() );
+            }
         }
     }
     {

@@ -363,6 +363,79 @@ def test_full_size_frame_properties():
     dev.close()
 
 
+def test_full_size_frame_properties_of_the_headline_scene():
+    """The same for the scene the metric is quoted on (BASELINE configs[2] class: 1 111 216 triangles,
+    1920x1080), 4 of its 1024 samples: finite, deterministic, the oracle's image on a band of scanlines,
+    and the closest-hit ray count the oracle makes on that band."""
+    import torch
+    W, H = 1920, 1080
+    sc = scenes.million_bunny(W, H)
+    flat = sc.initKdTree(16).flatten(1)
+    dev = DeviceScene(flat)
+    img = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    p = render_params(W, H, 32, 32, seed=1, sample_begin=512, sample_end=516)
+    rs = dev.render(p, img)
+    torch.cuda.synchronize()
+    a = img.cpu().numpy()
+    assert np.isfinite(a).all() and a.min() >= 0 and a.max() > 0
+    assert rs.paths == W * H * 4 and rs.rays_closest >= rs.paths and rs.passes == 1
+    img2 = torch.zeros_like(img)
+    dev.render(p, img2)
+    torch.cuda.synchronize()
+    assert torch.equal(img, img2)
+    r0, r1 = 600, 608  # through the bunny
+    pb = render_params(W, H, 32, 32, seed=1, sample_begin=512, sample_end=516, row_begin=r0, row_end=r1)
+    cpu, crs, _, _ = orc.oracle_render(flat.desc, pb, 0, threads=16)
+    check_images(a[r0:r1], cpu[r0:r1], 4)
+    band = torch.zeros_like(img)
+    brs = dev.render(pb, band)
+    torch.cuda.synchronize()
+    assert torch.equal(band[r0:r1], img[r0:r1]) and not band[:r0].any() and not band[r1:].any()
+    # (shadow rays: the kernels skip those whose light sample contributes nothing, the oracle traces them all)
+    assert brs.rays_closest == crs.rays_closest and brs.rays_any <= crs.rays_any
+    dev.close()
+
+
+def test_one_pass_of_half_a_billion_paths():
+    """The default pass size (paths_per_pass = 0: up to 2^30 paths, up to 82 % of the free memory)
+    on a frame that needs it: configs[1] at 1920x1080 with 272 samples per pixel is ONE pass of 564 M
+    paths (path ids beyond 2^29, a workspace of 122 GB).  (i) The image equals the same samples rendered
+    in 17 passes of 16 samples up to the order of the fp32 additions of the partial sums; (ii) the last
+    scanlines -- the last tiles of every strip, i.e. the highest path ids of the pass -- equal the
+    oracle's; (iii) the number of passes is what the rule gives for the memory that was free."""
+    import torch
+    W, H = 1920, 1080
+    sx, sy = 17, 16
+    spp = sx * sy
+    sc = scenes.bunny_pair(W, H)
+    flat = sc.initKdTree(16).flatten(1)
+    dev = DeviceScene(flat)
+    big = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free_b = torch.cuda.mem_get_info()[0]
+    per_path = (50 + 4) * 4
+    cap = min(int(0.82 * free_b) // per_path, 1 << 30)
+    want_passes = -(-spp // max(1, cap // (W * H)))
+    assert W * H * spp > 1 << 29
+    rs = dev.render(render_params(W, H, sx, sy, seed=3), big)
+    torch.cuda.synchronize()
+    assert rs.passes == want_passes and rs.paths == W * H * spp
+    if free_b > 160e9:
+        assert rs.passes == 1
+    dev.trim()
+    small = torch.zeros_like(big)
+    rs2 = dev.render(render_params(W, H, sx, sy, seed=3, paths_per_pass=W * H * 16), small)
+    torch.cuda.synchronize()
+    assert rs2.passes == 17 and (rs2.rays_closest, rs2.rays_any) == (rs.rays_closest, rs.rays_any)
+    a, b = big.cpu().numpy(), small.cpu().numpy()
+    assert np.isfinite(a).all() and np.allclose(a, b, rtol=3e-5, atol=1e-4)
+    r0, r1 = H - 8, H
+    cpu, _, _, _ = orc.oracle_render(flat.desc, render_params(W, H, sx, sy, seed=3, row_begin=r0, row_end=r1), 0, threads=16)
+    check_images(a[r0:r1], cpu[r0:r1], spp)
+    dev.close()
+
+
 def test_hip_renderer_and_single_ray_host_api():
     """The C++ host classes that mirror the reference (HIPRenderer next to CPURenderer, and
     intersectKdTree for one ray) give what the C-ABI gives directly."""
@@ -639,7 +712,8 @@ def test_render_rejects_bad_parameters():
                          (dict(sample_end=5), 1, "sample range"), (dict(sample_begin=3, sample_end=2), 1, "sample range"),
                          (dict(row_end=17), 1, "row range"), (dict(row_begin=9, row_end=8), 1, "row range"),
                          (dict(max_depth=63), 4, "max_depth"), (dict(max_depth=2 ** 32 - 1), 4, "max_depth"),
-                         (dict(spp_x=65536, spp_y=65536, sample_end=1), 4, "sample grid")]:
+                         (dict(spp_x=65536, spp_y=65536, sample_end=1), 4, "sample grid"),
+                         (dict(paths_per_pass=(1 << 30) + 1), 4, "paths_per_pass"), (dict(paths_per_pass=2 ** 32 - 1), 4, "paths_per_pass")]:
         got, msg = status(**kw)
         assert got == st and text in msg, (kw, got, msg)
     assert not img.any() or np.isfinite(img).all()
@@ -771,3 +845,64 @@ def test_asynchronous_renders_on_different_streams_are_ordered():
         assert torch.equal(a, want_a) and torch.equal(b, want_b)
         assert all(torch.equal(g, w) for g, w in zip(hits, want_hits))
     dev.close()
+
+
+def test_trim_gives_the_workspace_back_and_the_next_frame_is_the_same():
+    """mrt_scene_trim releases what a handle keeps between calls; free device memory goes up by the
+    workspace, and the frame rendered afterwards (with a fresh workspace) has the same bits."""
+    import torch
+    sc = scenes.small_bunny(128, 128, env_pixels=scenes.synthetic_env())
+    dev = DeviceScene(sc.initKdTree().flatten(1))
+    p = render_params(128, 128, 8, 8, max_depth=4, seed=2)
+    a = torch.zeros((128, 128, 3), device="cuda")
+    dev.render(p, a)
+    torch.cuda.synchronize()
+    held = torch.cuda.mem_get_info()[0]
+    dev.trim()
+    freed = torch.cuda.mem_get_info()[0] - held
+    assert freed >= 128 * 128 * 64 * 200, freed  # the path state of 1 M paths at 200 bytes each
+    b = torch.zeros_like(a)
+    dev.render(p, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and float(a.max()) > 0
+    dev.trim()
+    dev.trim()  # nothing left to give back: still fine
+    dev.close()
+
+
+def test_reduce_without_host_synchronisation():
+    """mrt_reduce_async: three handles render their sample ranges into their own images on three
+    different streams and the images are reduced on a fourth, twice in a row (the progressive loop),
+    without a host synchronisation in between; the sum equals the frame of one handle up to the order
+    of the fp32 additions."""
+    import ctypes as C
+    import torch
+    sc = scenes.small_bunny(96, 96, env_pixels=scenes.synthetic_env())
+    flat = sc.initKdTree().flatten(1)
+    devs = [DeviceScene(flat) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    handles = (C.c_void_p * 3)(*[d._h for d in devs])
+    keep = []  # every image stays alive until the device has finished
+    with torch.cuda.stream(streams[0]):
+        root = torch.zeros((96, 96, 3), device="cuda")
+    for step in range(2):  # samples [0, 8) then [8, 16), a third each; the root's image accumulates
+        imgs = [root]
+        for k in (1, 2):
+            with torch.cuda.stream(streams[k]):  # zeroed on the stream the handle renders on
+                imgs.append(torch.zeros((96, 96, 3), device="cuda"))
+        keep.append(imgs)
+        for k in range(3):
+            b, e = parallel.sample_range(k, 3, 8)
+            p = render_params(96, 96, 4, 4, max_depth=4, seed=9, sample_begin=step * 8 + b, sample_end=step * 8 + e)
+            devs[k].render(p, imgs[k], stream=streams[k].cuda_stream)
+        ptrs = (C.c_void_p * 3)(*[im.data_ptr() for im in imgs])
+        st = abi.hip().mrt_reduce_async(handles, ptrs, 3, 96 * 96 * 3, 0, streams[3].cuda_stream)
+        assert st == abi.MRT_OK, abi.hip().mrt_last_error().decode()
+    torch.cuda.synchronize()
+    one = torch.zeros((96, 96, 3), device="cuda")
+    devs[0].render(render_params(96, 96, 4, 4, max_depth=4, seed=9), one)
+    torch.cuda.synchronize()
+    got, want = root.cpu().numpy(), one.cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6) and want.max() > 0
+    for d in devs:
+        d.close()

@@ -346,9 +346,13 @@ def test_scene_create_validates_everything_a_kernel_indexes_with(built):
             return arr, texels
         return mutate
     assert try_create(image_texture(4, 4, 0))[0] in valid
-    for w, hgt, off in [(4, 4, 3), (5, 4, 0), (0, 4, 0), (4, 4, 2 ** 64 - 3), (65536, 65536, 0), (2 ** 32 - 1, 2 ** 32 - 1, 0)]:
+    for w, hgt, off in [(4, 4, 3), (5, 4, 0), (0, 4, 0), (4, 4, 2 ** 64 - 3), (65535, 65535, 0)]:
         st, msg, _ = try_create(image_texture(w, hgt, off))
         assert st == 1 and "texel pool" in msg, (w, hgt, off, st, msg)
+    # 65536 and beyond: refused outright (3 * w * h of 2^31 x 2863311531 wraps 64 bits to a window that "fits")
+    for w, hgt in [(65536, 65536), (2 ** 32 - 1, 2 ** 32 - 1), (2 ** 31, 2863311531), (65536, 1)]:
+        st, msg, _ = try_create(image_texture(w, hgt, 0))
+        assert st == 4 and "too large" in msg, (w, hgt, st, msg)
 
     rng = np.random.default_rng(5)
     tables = [("nodes", C.c_uint32, lambda d: 2 * d.n_nodes), ("refs", C.c_uint32, lambda d: d.n_refs),

@@ -73,3 +73,43 @@ def test_noalloc_rejects_oversize(built):
     assert st == 4  # MRT_ERR_UNSUPPORTED
     assert b"MRT_NOALLOC_MAX_RAYS" in abi.hip().mrt_last_error()
     dev.close()
+
+
+def test_noalloc_allocates_nothing_and_can_be_captured(built):
+    """Free device memory is the same before and after a call (mrt_intersect with device buffers
+    allocates nothing either once the scene exists, so the comparison is with the state right before),
+    and the call can be recorded into a HIP graph -- which refuses hipMalloc -- and replayed: the
+    replayed launch writes the same hits."""
+    import torch
+    sc = scenes.small_bunny(64, 64)
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    o, d = orc.camera_rays(flat.desc, 64, 64, seed=3)
+    n = len(o)
+    to, td = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    cols = [to[:, 0].contiguous(), to[:, 1].contiguous(), to[:, 2].contiguous(), td[:, 0].contiguous(), td[:, 1].contiguous(),
+            td[:, 2].contiguous(), torch.zeros(n, device="cuda"), torch.full((n,), 1e5, device="cuda")]
+    want = _noalloc(dev, cols, n, False, torch)  # warm: the kernel's code object is loaded, the occupancy asked for
+    torch.cuda.synchronize()
+    out = [torch.full((n,), -7, dtype=torch.int32, device="cuda:0")] + [torch.full((n,), -7.0, device="cuda:0") for _ in range(3)]
+    rays = abi.Rays(*[c.data_ptr() for c in cols])
+    hits = abi.Hits(*[x.data_ptr() for x in out])
+    free_before = torch.cuda.mem_get_info()[0]
+    st = abi.hip().mrt_intersect_noalloc(dev._h, n, C.byref(rays), C.byref(hits), abi.MRT_CLOSEST_HIT, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert st == abi.MRT_OK and torch.cuda.mem_get_info()[0] == free_before
+    for g, w in zip(out, want):
+        assert torch.equal(g, w)
+    for x in out:
+        x.fill_(-7)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = abi.hip().mrt_intersect_noalloc(dev._h, n, C.byref(rays), C.byref(hits), abi.MRT_CLOSEST_HIT, torch.cuda.current_stream().cuda_stream)
+    assert st == abi.MRT_OK, abi.hip().mrt_last_error().decode()
+    torch.cuda.synchronize()
+    assert int((out[0] == -7).all())  # capture records, it does not run
+    graph.replay()
+    torch.cuda.synchronize()
+    for g, w in zip(out, want):
+        assert torch.equal(g, w)
+    dev.close()
