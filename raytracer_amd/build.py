@@ -85,7 +85,7 @@ def build_ref(force=False):
     """Only in the build container: the reference sources do not travel."""
     if not os.path.isdir(os.path.join(REFERENCE, "src")):
         return None
-    if force or _newer(REF_SO, [os.path.join(ORACLE, "ref", "ref_harness.cpp")]):
+    if force or _newer(REF_SO, _files(os.path.join(ORACLE, "ref"), (".cpp",)) + [os.path.join(ORACLE, "Makefile")]):
         _run(["make", "-C", ORACLE, "ref"] + (["-B"] if force else []))
     return REF_SO
 

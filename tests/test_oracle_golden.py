@@ -523,3 +523,18 @@ def test_live_reference_random_cameras(built):
         lib.ref_camera_rays(cam, n, P(st), P(u2), P(ro), P(rd))
         o.orc_camera_rays(C.byref(oc), n, P(st), P(u2), P(oo), P(od))
         assert np.array_equal(bits(oo), bits(ro)) and np.array_equal(bits(od), bits(rd)), k
+
+
+@pytest.mark.ref
+def test_operand_order_of_the_bsdf_branch_cosine_as_gxx_builds_it(built):
+    """Compiler evidence, not parity.  integrator.cpp:96-98 multiplies sample(..., &wi, ...) -- which
+    writes wi -- by max(dot(normal, wi), 0) -- which reads it -- and C++ leaves the order of the two
+    operands open.  oracle/ref/eval_order_*.cpp give the class of the reference's own Material.h an
+    instrumented sample() in a translation unit of its own and evaluate a statement of exactly that
+    shape with oracle/Makefile's flags: g++ takes the cosine first, i.e. from the light-sample
+    direction still in wi.  That is the order the oracle (orc_shading.h) and the kernels
+    (device_render.hpp: cos_prev_wi) reproduce; if a compiler ever answers 0 here, both follow the
+    other order and this test says so."""
+    import ctypes as C
+    lib = C.CDLL(orc.REF_SO)
+    assert lib.ref_eval_order_probe() == 1
