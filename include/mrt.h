@@ -389,10 +389,19 @@ mrt_status mrt_scene_device_info( const mrt_scene* scene, mrt_device_info* out )
  * off, MRT_RELAY_AFTER=<trips> sets how long a wave goes on first (default 256; 0 in the tests). */
 mrt_status mrt_debug_relayed( mrt_scene* scene, uint64_t* out );
 
+/* Diagnostics: how mrt_render traces the camera rays on this handle -- *packets = 1 when the 64 samples a
+ * wave holds walk the tree together (wave-uniform nodes and primitives through scalar loads; faster
+ * where a triangle covers many pixels), 0 when they go through the streaming traversal like every
+ * other ray (faster where triangles are about a pixel wide).  Same hits either way, bit for bit.  Unless
+ * MRT_CAMERA_PACKETS=0 / 1 in the environment fixed it when the scene was created, the first mrt_render
+ * of an image size times both on three bands of scanlines (ms_stream, ms_packets: what it measured,
+ * 0 before) and keeps the faster. */
+mrt_status mrt_debug_camera_choice( const mrt_scene* scene, int32_t* packets, float* ms_stream, float* ms_packets );
+
 const char* mrt_last_error( void );
 /* The version of this header the library was built from (MRT_VERSION).  2: mrt_render_stats ends
  * with `passes` (a caller built against version 1 must not pass its shorter struct), mrt_scene_trim,
- * mrt_debug_relayed. */
+ * mrt_reduce_async, mrt_debug_relayed, mrt_debug_camera_choice. */
 #define MRT_VERSION 2
 int32_t mrt_version( void );
 

@@ -141,6 +141,9 @@ def hip():
             lib.mrt_reduce_async.restype = C.c_int32
             lib.mrt_scene_trim.argtypes = [C.c_void_p]
             lib.mrt_scene_trim.restype = C.c_int32
+        if hasattr(lib, "mrt_debug_camera_choice"):
+            lib.mrt_debug_camera_choice.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+            lib.mrt_debug_camera_choice.restype = C.c_int32
         lib.mrt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
         lib.mrt_render_multi.restype = C.c_int32
         lib.mrt_debug_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32]

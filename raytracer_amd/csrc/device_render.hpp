@@ -245,6 +245,16 @@ __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_cam
     if ( STATS ) flush_stats( st, stats );
 }
 
+// The same with the 64 rays of a wave walking the tree together (trace_packets): consecutive paths are
+// samples of one pixel, whose camera rays differ by a lens offset and a sub-pixel jitter.
+#ifndef MRT_PACKET_WAVES
+#define MRT_PACKET_WAVES 8
+#endif
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_PACKET_WAVES ) extend_camera_packet_kernel( DTrace tr, CameraIO io, uint32_t n, uint32_t* __restrict__ deal ) {
+    __shared__ uint32_t lds[MRT_XF_LDS * 12];
+    trace_packets( tr, (lds_u32*)lds, io, n, deal );
+}
+
 // STATS (all traversal kernels of this file): also count the visited nodes, leaves, references
 // and primitive tests into stats[0..3].
 template <bool STATS>

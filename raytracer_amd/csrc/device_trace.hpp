@@ -782,6 +782,224 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     while ( trip( std::true_type {} ) ) {}
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packet traversal: the 64 rays a wave holds walk the tree TOGETHER.
+//
+// For rays that start at (nearly) one point and differ little in direction -- the samples of one
+// pixel -- every lane of the streaming traversal above fetches the same records, keeps the same stack
+// and pays the state machine's bookkeeping for it, and the kernel is bound by instruction issue, not by
+// memory.  Here the node a wave is at, the stack of deferred nodes and the primitive under test are
+// wave-uniform: records, references and primitives arrive through scalar loads, the per-lane work is
+// the reference's arithmetic and nothing else (the split distance, the primitive test), and a mask
+// says which lanes take part.
+//
+// Every lane still makes exactly the decisions of its own traversal, on its own interval, in its own
+// front-to-back order:
+//   - at an inner node every participating lane classifies itself (near only / far only / both) from
+//     its own t = (split - o[axis]) / d[axis] and interval; the wave goes to the near child with the
+//     lanes that want it and defers the far child with the lanes that want that (those that want both
+//     shorten their interval to [a, t] and get [t, b] back when the deferred node is taken up: the b
+//     they had is kept per lane with the deferred node, the new a is the b they come back with, as in
+//     the single-ray traversal);
+//   - which child is the near one depends on the lane's side of the split plane.  Lanes that disagree
+//     (origins on both sides: only possible where the plane cuts through the lens) are split: the wave
+//     goes on with those for which the left child is near and defers THE SAME NODE for the others;
+//   - at a leaf the participating lanes test the leaf's primitives in stored order against their own
+//     [a, b]; a lane that has accepted a hit in a leaf is finished and leaves every mask.
+// A lane that does not take part in a subtree keeps its interval untouched, deferred nodes are taken up
+// last-in first-out, so each lane meets its leaves in the order and with the intervals of its own
+// traversal: same hit, same distance, bit for bit, for ANY 64 rays -- coherence only decides the speed.
+// Closest-hit rays only.  The deferred-node stack lives in per-lane scratch arrays (a deferred node's
+// words in lanes 0-5 of one array, every lane's old b in another).
+#define MRT_PACKET_STACK ( 2 * MRT_STACK_MAX ) // per tree level at most one deferred child and one deferred "other side"
+typedef uint32_t v4u __attribute__( ( ext_vector_type( 4 ) ) );
+typedef __attribute__( ( address_space( 4 ) ) ) const v4u const_u4;         // constant address space:
+typedef __attribute__( ( address_space( 4 ) ) ) const uint32_t const_u32;   // loads at wave-uniform addresses are scalar loads
+
+template <class IO>
+MRT_DEV void trace_packets( const DTrace& s, lds_u32* lds, const IO& io, uint32_t n, uint32_t* deal ) {
+    const lds_f32* xf_lds = (const lds_f32*)lds;
+    stage_transforms( s, (lds_f32*)lds );
+    const_u4* const cnodes  = (const_u4*)(uintptr_t)s.nodes;
+    const_u32* const crefs  = (const_u32*)(uintptr_t)s.refs;
+    const_u4* const cprims  = (const_u4*)(uintptr_t)s.prims;
+    const uint32_t lane     = __lane_id();
+    const unsigned long long my_bit = 1ull << lane;
+    uint32_t st_words[MRT_PACKET_STACK]; // deferred node e: lane 0 its reference, 1-2 the lanes that enter it, 3-4 those of them whose interval is restored, 5 its kind
+    uint32_t st_b[MRT_PACKET_STACK];     // every lane's b at the time node e was deferred
+
+    const uint32_t n_chunks = ( n + ( MRT_CHUNK - 1u ) ) / MRT_CHUNK;
+    for ( uint32_t part_try = 0; part_try < 8u; ) {
+        // the next chunk of this XCD's part of the list, then of the other parts (as in trace_stream)
+        const uint32_t part = ( ( blockIdx.x & s.xcd_mask ) + part_try ) & 7u;
+        uint32_t got        = 0;
+        if ( lane == 0 ) got = atomicAdd( deal + part * MRT_DEAL_STRIDE, 1u );
+        got              = (uint32_t)__builtin_amdgcn_readfirstlane( (int)got );
+        const uint32_t c = ( ( got / MRT_DEAL_RUN ) * 8u + part ) * MRT_DEAL_RUN + got % MRT_DEAL_RUN;
+        if ( c >= n_chunks ) {
+            part_try++;
+            continue;
+        }
+        for ( uint32_t base = c * MRT_CHUNK; base < ( c + 1u ) * MRT_CHUNK && base < n; base += 64u ) {
+            // ------------------------------------------------------------ fetch
+            const uint32_t idx = base + lane;
+            const bool valid   = idx < n;
+            uint32_t tag       = 0;
+            V3 o = mk3( 0.f ), d = mk3( 0.f );
+            float a = 0.f, b = 0.f, ray_tmax = 0.f;
+            bool in = false; // this lane takes part in the subtree the wave is in
+            if ( valid ) {
+                io.load( idx, tag, o, d, a, ray_tmax );
+                b  = ray_tmax;
+                // (a NaN ray fails every test of the reference after walking the whole tree: same result without the walk)
+                in = !( isnan( o.x ) | isnan( o.y ) | isnan( o.z ) | isnan( d.x ) | isnan( d.y ) | isnan( d.z ) ) && clip_root( s, o, d, a, b );
+            }
+            unsigned long long act = __ballot( in ), done = 0ull;
+            float tmax = 0.f, hu = 0.f, hv = 0.f;
+            uint32_t hprim = 0;
+            bool has       = false;
+            V3 xro = o, xrd = d; // object-space ray under transform xr_id (wave-uniform)
+            uint32_t xr_id = 0;
+            uint32_t ref   = 0; // where the wave is: bits 0-29 a record, bit 31 set = one of its children (bit 30: the right one), else its head
+            uint32_t sp    = 0;
+            uint32_t cur_rec = 0xffffffffu;
+            v4u R0 = { 0u, 0u, 0u, 0u }, R1 = R0;
+            // ------------------------------------------------------------ walk
+            for ( ;; ) {
+                if ( act == 0ull ) { // take up the last deferred node some unfinished lane enters
+                    bool found_one = false;
+                    while ( sp > 0u ) {
+                        --sp;
+                        const uint32_t w  = st_words[sp];
+                        const unsigned long long m_enter = ( (unsigned long long)(uint32_t)__builtin_amdgcn_readlane( (int)w, 2 ) << 32 | (uint32_t)__builtin_amdgcn_readlane( (int)w, 1 ) ) & ~done;
+                        if ( m_enter == 0ull ) continue;
+                        const unsigned long long m_restore = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane( (int)w, 4 ) << 32 | (uint32_t)__builtin_amdgcn_readlane( (int)w, 3 );
+                        ref = (uint32_t)__builtin_amdgcn_readlane( (int)w, 0 );
+                        act = m_enter;
+                        in  = ( act & my_bit ) != 0ull;
+                        if ( in && ( m_restore & my_bit ) ) {
+                            a = b;
+                            b = __uint_as_float( st_b[sp] );
+                        }
+                        found_one = true;
+                        break;
+                    }
+                    if ( !found_one ) break;
+                }
+                const uint32_t rec = (uint32_t)__builtin_amdgcn_readfirstlane( (int)( ref & 0x3fffffffu ) );
+                if ( rec != cur_rec ) {
+                    R0      = cnodes[2u * rec];
+                    R1      = cnodes[2u * rec + 1u];
+                    cur_rec = rec;
+                }
+                // the node the wave is at: an inner node (split, axis, its two children as references) or a leaf
+                float split;
+                uint32_t axis, ref_l, ref_r;
+                bool leaf = false;
+                uint32_t w0 = 0, w1 = 0, r0 = 0;
+                if ( !( ref & 0x80000000u ) && ( R0.y & 3u ) != 3u ) { // the head of the record
+                    split = __uint_as_float( R0.x ), axis = R0.y & 3u;
+                    ref_l = rec | 0x80000000u, ref_r = rec | 0xc0000000u;
+                }
+                else { // a child (a head with "axis" 3 is no node: the left slot is the record's node)
+                    const bool right = ( ref & 0x80000000u ) && ( ref & 0x40000000u );
+                    w0 = right ? R1.x : R0.z, w1 = right ? R1.y : R0.w, r0 = right ? R1.w : R1.z;
+                    leaf  = ( w1 & 3u ) == 3u;
+                    split = __uint_as_float( w0 ), axis = w1 & 3u;
+                    ref_l = w1 >> 2, ref_r = ( w1 >> 2 ) + 1u;
+                }
+                if ( !leaf ) {
+                    const float diff = split - comp( o, (int)axis );
+                    const float t    = diff / comp( d, (int)axis );
+                    const bool lnear = diff > 0.0f;
+                    const unsigned long long m_l = __ballot( in & lnear ), m_r = __ballot( in & !lnear );
+                    bool near_left = m_l != 0ull;
+                    if ( m_l != 0ull && m_r != 0ull ) { // origins on both sides of the plane: this node again, later, for the other side
+                        st_words[sp] = lane == 0u ? ref : lane == 1u ? (uint32_t)m_r : lane == 2u ? (uint32_t)( m_r >> 32 ) : 0u;
+                        sp++;
+                        act = m_l;
+                        in  = in & lnear;
+                    }
+                    const bool near_only = ( t > b ) | ( t < 0.0f );
+                    const bool far_only  = !near_only & ( t < a );
+                    const bool both      = !near_only & !far_only;
+                    const unsigned long long m_n = __ballot( in & !far_only ), m_f = __ballot( in & !near_only ), m_b = __ballot( in & both );
+                    const uint32_t ref_n = near_left ? ref_l : ref_r, ref_f = near_left ? ref_r : ref_l;
+                    if ( m_n == 0ull ) {
+                        act = m_f;
+                        ref = ref_f;
+                    }
+                    else {
+                        if ( m_f != 0ull ) {
+                            st_words[sp] = lane == 0u ? ref_f : lane == 1u ? (uint32_t)m_f : lane == 2u ? (uint32_t)( m_f >> 32 ) : lane == 3u ? (uint32_t)m_b : lane == 4u ? (uint32_t)( m_b >> 32 ) : 0u;
+                            st_b[sp]     = __float_as_uint( b );
+                            sp++;
+                        }
+                        b   = ( in & both ) ? t : b;
+                        act = m_n;
+                        in  = in & !far_only;
+                        ref = ref_n;
+                    }
+                    continue;
+                }
+                // ------------------------------------------------------------ leaf: the interval becomes [a, b]
+                if ( in ) {
+                    tmax = b;
+                    has  = false;
+                }
+                const uint32_t cnt = w1 >> 2;
+                for ( uint32_t k = 0; k < cnt; k++ ) {
+                    const uint32_t obj = k == 0u ? r0 : crefs[w0 + k];
+                    const v4u q0 = cprims[obj * MRT_PRIM_Q], q1 = cprims[obj * MRT_PRIM_Q + 1u], q2 = cprims[obj * MRT_PRIM_Q + 2u];
+                    const uint32_t flags = q0.w, xf = flags >> MRT_PRIM_XF_SHIFT;
+                    if ( xf != xr_id ) {
+                        xro = o, xrd = d;
+                        if ( xf != 0u ) transform_ray( s, xf_lds, xf, o, d, xro, xrd );
+                        xr_id = xf;
+                    }
+                    float t = 0.f, u = 0.f, v = 0.f, det = 0.f;
+                    bool outside = true, hit = false;
+                    if ( ( flags & 3u ) == MRT_PRIM_TRI ) {
+                        hit     = tri_test( xro, xrd, make_float4( __uint_as_float( q0.x ), __uint_as_float( q0.y ), __uint_as_float( q0.z ), 0.f ),
+                                            make_float4( __uint_as_float( q1.x ), __uint_as_float( q1.y ), __uint_as_float( q1.z ), __uint_as_float( q1.w ) ),
+                                            make_float2( __uint_as_float( q2.x ), __uint_as_float( q2.y ) ), a, tmax, t, u, v, det );
+                        outside = !( det < 0.f );
+                    }
+                    else { hit = sphere_test( s, xf_lds, xf, xro, xrd, o, d, a, tmax, t, outside ); }
+                    // a later hit replaces the current one only if strictly nearer (see trace_stream)
+                    const bool keep = in & hit & ( !has | ( t < tmax ) );
+                    tmax            = keep ? t : tmax;
+                    hprim           = keep ? ( obj | ( outside ? 0x80000000u : 0u ) ) : hprim;
+                    hu              = keep ? u : hu;
+                    hv              = keep ? v : hv;
+                    has             = has | keep;
+                }
+                // the search ends at the first leaf that produced a hit
+                done |= __ballot( in & has );
+                act = 0ull;
+                in  = false;
+            }
+            // ------------------------------------------------------------ retire
+            if ( valid ) {
+                DHit h;
+                h.prim    = has ? (int32_t)( hprim & 0x7fffffffu ) : -1;
+                h.t       = has ? tmax : ray_tmax;
+                h.u       = has ? hu : 0.f;
+                h.v       = has ? hv : 0.f;
+                h.outside = has ? hprim >> 31 : 0u;
+                bool found = has;
+                if ( s.n_out != 0u ) {
+                    v4f rec4;
+                    uint32_t tested;
+                    const bool has_pl = scan_planes<false>( s, xf_lds, o, d, ray_tmax, rec4, tested );
+                    found             = merge_plane<false>( has, h, has_pl, rec4 );
+                }
+                io.store( tag, found, h );
+            }
+        }
+    }
+}
+
 // A hit as one 16-byte record: (prim | outside << 31 as bits, or 0xffffffff for a miss; t; u; v).
 MRT_DEV float4 pack_hit( const DHit& h ) {
     const uint32_t bits = h.prim < 0 ? 0xffffffffu : ( (uint32_t)h.prim | ( h.outside ? 0x80000000u : 0u ) );

@@ -157,6 +157,16 @@ struct mrt_scene {
     DevBuf<float> reduce_staging;  // mrt_reduce: where the other handles' images land on this (the root's) device
     uint32_t relay_after = MRT_RELAY_AFTER_DEFAULT;
     bool relay_on        = true;
+    // How the first bounce's rays are traced: -1 = whichever of the two traversals is faster for this scene
+    // and frame (timed once per image size on three bands of scanlines, see mrt_render), 0 = the streaming
+    // traversal, 1 = as packets (trace_packets).  MRT_CAMERA_PACKETS=0 / 1 in the environment fixes it.
+    int camera_mode      = -1;
+    struct {
+        uint32_t width = 0, height = 0, n_samples = 0;
+        int packets = 0;
+        float ms_stream = 0.f, ms_packets = 0.f;
+    } camera_choice; // what was measured last
+    bool intersect_packets = false; // tests: mrt_intersect's closest-hit rays go through trace_packets as well
     uint32_t tree_depth = 0;
     int n_cus           = 256;
     bool no_emitters    = false; // no object has a material with a non-zero emission component
@@ -587,6 +597,14 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
         const char* e = std::getenv( "MRT_RELAY" );
         s->relay_on   = !( e && std::strcmp( e, "0" ) == 0 );
         if ( const char* a = std::getenv( "MRT_RELAY_AFTER" ) ) s->relay_after = (uint32_t)std::strtoul( a, nullptr, 10 );
+        // MRT_CAMERA_PACKETS=1 / 0: the camera rays of a pixel always / never walk the tree together
+        // (trace_packets; by default mrt_render times both traversals once and keeps the faster: packets win
+        // where a triangle covers many pixels, the streaming traversal where triangles are about a pixel wide);
+        // MRT_INTERSECT_PACKETS=1: mrt_intersect's closest-hit batches through the packet traversal (tests)
+        e                    = std::getenv( "MRT_CAMERA_PACKETS" );
+        s->camera_mode       = e && std::strcmp( e, "1" ) == 0 ? 1 : ( e && std::strcmp( e, "0" ) == 0 ? 0 : -1 );
+        e                    = std::getenv( "MRT_INTERSECT_PACKETS" );
+        s->intersect_packets = e && std::strcmp( e, "1" ) == 0;
         if ( s->relay_on )
             for ( int k = 0; k < 3; k++ ) {
                 HIP_TRY( s->relay[k].list.alloc( MRT_RELAY_CAP ) );
@@ -642,6 +660,14 @@ mrt_status mrt_scene_device_info( const mrt_scene* scene, mrt_device_info* out )
     out->compute_units = scene->n_cus;
     out->xcd_mask      = scene->trace.xcd_mask;
     out->kd_tree_depth = scene->tree_depth;
+    return MRT_OK;
+}
+
+mrt_status mrt_debug_camera_choice( const mrt_scene* scene, int32_t* packets, float* ms_stream, float* ms_packets ) {
+    if ( !scene || !packets ) return fail( MRT_ERR_INVALID, "NULL argument" );
+    *packets = scene->camera_mode >= 0 ? scene->camera_mode : scene->camera_choice.packets;
+    if ( ms_stream ) *ms_stream = scene->camera_choice.ms_stream;
+    if ( ms_packets ) *ms_packets = scene->camera_choice.ms_packets;
     return MRT_OK;
 }
 
@@ -706,6 +732,11 @@ __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) trace_batc
     DStats st { 0, 0, 0, 0 };
     trace_stream<ANY, false, STATS>( s, lp, io, n, deal, st, relay );
     if ( STATS ) flush_stats( st, stats );
+}
+
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_PACKET_WAVES ) trace_batch_packet_kernel( DTrace s, BatchIO io, uint32_t n, uint32_t* __restrict__ deal ) {
+    __shared__ uint32_t lds[MRT_XF_LDS * 12];
+    trace_packets( s, (lds_u32*)lds, io, n, deal );
 }
 
 // The follow-up launches of a traversal launch that ran with the relay `r` (device_trace.hpp: Relay)
@@ -796,6 +827,9 @@ extern "C" mrt_status mrt_intersect( mrt_scene* sc,
     if ( flags == MRT_ANY_HIT ) {
         if ( stats ) LAUNCH( true, true );
         else LAUNCH( true, false );
+    }
+    else if ( sc->intersect_packets && !stats ) {
+        hipLaunchKernelGGL( trace_batch_packet_kernel, dim3( trace_grid_blocks( trace_batch_packet_kernel, n, sc->n_cus ) ), block, 0, stream, sc->trace, io, (uint32_t)n, words );
     }
     else {
         if ( stats ) LAUNCH( false, true );

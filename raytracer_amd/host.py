@@ -355,6 +355,13 @@ class DeviceScene:
         if abi.hip().mrt_scene_trim(self._h) != abi.MRT_OK:
             raise MrtError(abi.hip().mrt_last_error().decode())
 
+    def camera_choice(self):
+        """mrt_debug_camera_choice: (packets 0 / 1, ms streaming, ms packets) of the handle's camera rays."""
+        k, a, b = C.c_int32(), C.c_float(), C.c_float()
+        if abi.hip().mrt_debug_camera_choice(self._h, C.byref(k), C.byref(a), C.byref(b)) != abi.MRT_OK:
+            raise MrtError(abi.hip().mrt_last_error().decode())
+        return k.value, a.value, b.value
+
     def relayed(self):
         """mrt_debug_relayed: rays this handle's traversal launches have handed over so far."""
         n = C.c_uint64()

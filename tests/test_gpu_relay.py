@@ -107,3 +107,39 @@ def test_frames_with_and_without_the_relay_are_the_same_bits(built, monkeypatch,
     for f in frames[1:]:
         assert np.array_equal(f[0], frames[0][0]) and f[1:3] == frames[0][1:3]
     assert frames[0][0].max() > 0
+
+
+@pytest.mark.parametrize("name", ["cornell", "bunny_plane", "veach"])
+def test_camera_rays_as_packets_give_the_same_frame(built, monkeypatch, name):
+    """The camera rays of a pixel walking the tree together (trace_packets, MRT_CAMERA_PACKETS=1), through
+    the streaming traversal (=0), or whichever the library's timing picks (unset): the same frame bit for
+    bit.  With MRT_INTERSECT_PACKETS=1 mrt_intersect's closest-hit batches go through the packet traversal:
+    hit ids and distances equal the oracle's on camera rays, random rays and short rays, and all four
+    output arrays equal the streaming traversal's."""
+    sc = _scene(name)
+    w, h = (96, 54) if name == "veach" else (96, 96)
+    flat = sc.initKdTree().flatten(1)
+    frames = []
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("MRT_CAMERA_PACKETS", raising=False)
+        else:
+            monkeypatch.setenv("MRT_CAMERA_PACKETS", mode)
+        dev = DeviceScene(flat)
+        img = np.zeros((h, w, 3), np.float32)
+        rs = dev.render(render_params(w, h, 8, 8, max_depth=4, seed=6, paths_per_pass=w * h * 40), img)
+        choice = dev.camera_choice()
+        assert choice[0] == int(mode) if mode is not None else (choice[0] in (0, 1) and choice[1] > 0 and choice[2] > 0)
+        frames.append((img, rs.rays_closest, rs.rays_any))
+        dev.close()
+    for f in frames[1:]:
+        assert np.array_equal(f[0], frames[0][0]) and f[1:] == frames[0][1:]
+    plain = DeviceScene(flat)
+    monkeypatch.setenv("MRT_INTERSECT_PACKETS", "1")
+    dev = DeviceScene(flat)
+    o, d, tmin, tmax = _rays(flat, 96, 96, 30000, 23)
+    assert _compare(flat, dev, o, d, tmin, tmax, False) > 1000
+    for x, y in zip(dev.intersect(o, d, tmin, tmax), plain.intersect(o, d, tmin, tmax)):  # prim, t, u, v of every ray, misses included
+        assert np.array_equal(_bits(x) if x.dtype == np.float32 else x, _bits(y) if y.dtype == np.float32 else y)
+    dev.close()
+    plain.close()
