@@ -41,15 +41,17 @@ struct PathState {
     float *tpx, *tpy, *tpz; // throughput
     float *Lx, *Ly, *Lz;    // radiance so far
     uint64_t* rng_state; // PCG32 state of the sample's engine stream (its increment follows from the sample's key)
-    // pending direct lighting of the last shaded bounce: L += (ptp * di) / pick_pdf
-    float *ptx, *pty, *ptz, *dix, *diy, *diz, *pick_pdf;
+    // pending direct lighting of the last shaded bounce: L += (ptp * di) / (the light pick's pdf, a
+    // constant of the scene: UniformLightDistribution, LightDistribution.cpp:5-12); ptp is not stored
+    // for a path's first bounce, where it is (1, 1, 1) (MRT_PENDING_TP_ONE)
+    float *ptx, *pty, *ptz, *dix, *diy, *diz;
     uint32_t* pending;
     // factors of the MIS ray's contribution; in a scene without emissive objects (mb) is the whole
     // contribution the ray makes if it escapes, and mw, mpdf, mlight are unused
     float *mbx, *mby, *mbz, *mw, *mpdf;
     uint32_t* mlight;
 };
-#define MRT_PATH_WORDS 50
+#define MRT_PATH_WORDS 49
 
 MRT_DEV void put_ray( float4* r0, float4* r1, uint32_t id, V3 o, V3 d, float tmax ) {
     r0[id] = make_float4( o.x, o.y, o.z, d.x );
@@ -205,12 +207,35 @@ struct ExtendIO {
     PathRays rays() const { return PathRays { ps.ray0, ps.ray1 }; }
 };
 
-// The first bounce makes its camera rays itself: the ray of path i -- Sampler::GetCameraSample
-// (sampler.cpp:43-49: 2D dimension 0, 1D dimension 0 = time, unused, 2D dimension 1) and
-// SimpleCamera::get_ray -- is computed when a lane takes it, stored for shade, and traced.  There
-// is no generate pass and no reading back of what it would have written (+1.2 % on the frame).
-// Throughput 1, radiance 0, no pending term and the start of the engine stream are what the first
-// shade of a path assumes without reading them.
+// The first bounce makes its camera rays itself: the ray of path i is computed when a lane takes it
+// and traced.  There is no generate pass and no reading back of what it would have written (+1.2 % on
+// the frame).  Throughput 1, radiance 0, no pending term and the start of the engine stream are what
+// the first shade of a path assumes without reading them.
+// The camera ray of path `id` of a pass: Sampler::GetCameraSample (sampler.cpp:43-49: 2D dimension 0,
+// 1D dimension 0 = time, unused, 2D dimension 1) and SimpleCamera::get_ray.  A function of the path id
+// alone, so nobody stores it: the first extend and the first shade each compute it (64 bytes of path
+// state less written and read back per camera sample), and so does a relay launch.
+MRT_DEV void camera_path_ray( const PassInfo& pi, const DCamera& cam, uint32_t id, V3& o, V3& d ) {
+    uint32_t s_local, p_local;
+    pass_split( pi, id, s_local, p_local );
+    uint32_t x, y;
+    pass_pixel( pi, p_local, x, y );
+    const uint32_t pixel  = y * pi.width + x;
+    const uint32_t sample = pi.sample_begin + s_local;
+    const uint64_t key    = pixel_key( pi.seed, pixel );
+    V2 jit  = strat2d( key, 0, sample, pi.spp_x, pi.spp_y );
+    V2 lens = strat2d( key, 1, sample, pi.spp_x, pi.spp_y );
+    camera_ray( cam, (float)x + jit.x, (float)y + jit.y, lens.x, lens.y, o, d );
+}
+#define MRT_CAMERA_TMAX 100000.f
+struct CameraRays {
+    PassInfo pi;
+    DCamera cam;
+    MRT_DEV void reload( uint32_t id, V3& o, V3& d, float& tmax ) const {
+        camera_path_ray( pi, cam, id, o, d );
+        tmax = MRT_CAMERA_TMAX;
+    }
+};
 struct CameraIO {
     static constexpr bool is_segment_io = false;
     PathState ps;
@@ -218,23 +243,15 @@ struct CameraIO {
     DCamera cam;
     MRT_DEV void load( uint32_t i, uint32_t& id, V3& o, V3& d, float& t0, float& t1 ) const {
         id = i;
-        uint32_t s_local, p_local;
-        pass_split( pi, id, s_local, p_local );
-        uint32_t x, y;
-        pass_pixel( pi, p_local, x, y );
-        const uint32_t pixel  = y * pi.width + x;
-        const uint32_t sample = pi.sample_begin + s_local;
-        const uint64_t key    = pixel_key( pi.seed, pixel );
-        V2 jit  = strat2d( key, 0, sample, pi.spp_x, pi.spp_y );
-        V2 lens = strat2d( key, 1, sample, pi.spp_x, pi.spp_y );
-        camera_ray( cam, (float)x + jit.x, (float)y + jit.y, lens.x, lens.y, o, d );
-        t0 = 0.f, t1 = 100000.f;
-        put_ray( ps.ray0, ps.ray1, id, o, d, t1 );
+        camera_path_ray( pi, cam, id, o, d );
+        t0 = 0.f, t1 = MRT_CAMERA_TMAX;
     }
     MRT_DEV void store( uint32_t id, bool, const DHit& h ) const { put_hit( ps.hit, id, h ); }
-    // the ray load() stored
-    MRT_DEV void reload( uint32_t id, V3& o, V3& d, float& t1 ) const { get_ray( ps.ray0, ps.ray1, id, o, d, t1 ); }
-    PathRays rays() const { return PathRays { ps.ray0, ps.ray1 }; }
+    MRT_DEV void reload( uint32_t id, V3& o, V3& d, float& t1 ) const {
+        camera_path_ray( pi, cam, id, o, d );
+        t1 = MRT_CAMERA_TMAX;
+    }
+    CameraRays rays() const { return CameraRays { pi, cam }; }
 };
 template <bool STATS>
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_camera_kernel( DTrace tr, CameraIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
@@ -270,15 +287,23 @@ __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_ker
 // The pending word of a path: byte 0 = a direct-lighting term is pending, byte 2 = its MIS ray
 // escaped (written, as a single byte, by connect_mis_occlusion; the term shade stored in mb for that
 // case is then part of DI).  shade writes the whole word, which clears byte 2.
+// Byte 1 = the term's throughput factor is (1, 1, 1) and was not stored (a path's first bounce).
 #define MRT_PENDING 0x000000ffu
+#define MRT_PENDING_TP_ONE 0x0000ff00u
 #define MRT_PENDING_MIS_ESCAPED 0x00ff0000u
-MRT_DEV void fold_pending( PathState& ps, uint32_t id, V3& L ) {
+// pick_pdf: the pdf of the light pick, Distribution1D::SampleDiscrete's func[offset] / (funcInt * count)
+// (sampling.h:103-111), the same for every light of a UniformLightDistribution
+MRT_DEV float light_pick_pdf( float func_int, uint32_t n_lights ) {
+    return ( func_int > 0 ) ? 1.f / ( func_int * (int)n_lights ) : 0;
+}
+MRT_DEV void fold_pending( PathState& ps, uint32_t id, V3& L, float pick_pdf ) {
     const uint32_t w = ps.pending[id];
     if ( !( w & MRT_PENDING ) ) return;
     // ret += throughput * directIllumination(...) / lightPdf   (integrator.cpp:169-177)
-    V3 tp = mk3( ps.ptx[id], ps.pty[id], ps.ptz[id] ), di = mk3( ps.dix[id], ps.diy[id], ps.diz[id] );
+    V3 tp = mk3( 1.f ), di = mk3( ps.dix[id], ps.diy[id], ps.diz[id] );
+    if ( !( w & MRT_PENDING_TP_ONE ) ) tp = mk3( ps.ptx[id], ps.pty[id], ps.ptz[id] );
     if ( w & MRT_PENDING_MIS_ESCAPED ) di = di + mk3( ps.mbx[id], ps.mby[id], ps.mbz[id] ); // integrator.cpp:114-117
-    L     = L + ( tp * di ) / ps.pick_pdf[id];
+    L     = L + ( tp * di ) / pick_pdf;
     ps.pending[id] = 0;
 }
 
@@ -381,13 +406,16 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
 #endif
         if ( depth != 0 ) {
             L = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
-            fold_pending( ps, id, L );
+            fold_pending( ps, id, L, light_pick_pdf( sh.light_func_int, sh.n_lights ) );
             tp = mk3( ps.tpx[id], ps.tpy[id], ps.tpz[id] );
         }
         bool pending = false;
         V3 ro, rd;
-        float ray_far;
-        get_ray( ps.ray0, ps.ray1, id, ro, rd, ray_far );
+        if ( FIRST ) camera_path_ray( pi, sh.cam, id, ro, rd ); // nobody stored it
+        else {
+            float ray_far;
+            get_ray( ps.ray0, ps.ray1, id, ro, rd, ray_far );
+        }
         DHit h;
         get_hit( ps.hit, id, h );
         if ( h.prim < 0 ) {
@@ -498,10 +526,9 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
                             }
                         }
                     }
-                    ps.ptx[id] = tp.x, ps.pty[id] = tp.y, ps.ptz[id] = tp.z;
+                    if ( !FIRST ) ps.ptx[id] = tp.x, ps.pty[id] = tp.y, ps.ptz[id] = tp.z; // (1, 1, 1) in a first bounce: MRT_PENDING_TP_ONE
                     ps.dix[id] = di.x, ps.diy[id] = di.y, ps.diz[id] = di.z;
-                    ps.pick_pdf[id] = lightPickPdf;
-                    pending         = true;
+                    pending    = true; // (lightPickPdf is light_pick_pdf(): the fold computes it again)
                 }
             }
             // integrator.cpp:180-193
@@ -521,7 +548,7 @@ __global__ void __launch_bounds__( MRT_SHADE_BLOCK, MRT_SHADE_WAVES ) shade_kern
             }
         }
         // fold_pending cleared the flag of a later bounce; the first one finds it unwritten
-        if ( pending || depth == 0 ) ps.pending[id] = pending ? 1u : 0u; // the whole word: no MIS ray has escaped yet
+        if ( pending || depth == 0 ) ps.pending[id] = pending ? ( FIRST ? 0x0101u : 1u ) : 0u; // the whole word: no MIS ray has escaped yet
         ps.Lx[id] = L.x, ps.Ly[id] = L.y, ps.Lz[id] = L.z;
     }
     uint32_t* const queues[3] = { q.next, q.shadow, q.mis };
@@ -669,7 +696,8 @@ __global__ void __launch_bounds__( 256 ) mis_resolve_kernel( DTrace tr, DShade s
 // Tiled pass (a pixel's samples are consecutive paths): a block takes 64 pixels; its waves load 64
 // samples of one pixel at a time (coalesced) into an LDS tile, then one lane per pixel and colour
 // channel adds that pixel's 64 values in order.
-__global__ void __launch_bounds__( 256 ) accumulate_pixel_kernel( PathState ps, PassInfo pi, float* __restrict__ rgb_sum ) {
+__global__ void __launch_bounds__( 256 ) accumulate_pixel_kernel( PathState ps, PassInfo pi, float* __restrict__ rgb_sum, float func_int, uint32_t n_lights ) {
+    const float pick_pdf = light_pick_pdf( func_int, n_lights );
     __shared__ float tile[3][64][65];
     const uint32_t p0 = blockIdx.x * 64u, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     float sum = 0.f; // of pixel p0 + lane, channel `wave` (waves 0..2)
@@ -680,7 +708,7 @@ __global__ void __launch_bounds__( 256 ) accumulate_pixel_kernel( PathState ps, 
             if ( p < pi.n_pixels && s < pi.n_samples ) {
                 const uint32_t id = pass_path( pi, s, p );
                 L                 = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
-                fold_pending( ps, id, L );
+                fold_pending( ps, id, L, pick_pdf );
             }
             tile[0][r][lane] = L.x, tile[1][r][lane] = L.y, tile[2][r][lane] = L.z;
         }
@@ -698,14 +726,15 @@ __global__ void __launch_bounds__( 256 ) accumulate_pixel_kernel( PathState ps, 
 }
 
 // Any other pass (the samples of a pixel are n_pixels apart): one thread per pixel.
-__global__ void __launch_bounds__( 256 ) accumulate_kernel( PathState ps, PassInfo pi, float* __restrict__ rgb_sum ) {
+__global__ void __launch_bounds__( 256 ) accumulate_kernel( PathState ps, PassInfo pi, float* __restrict__ rgb_sum, float func_int, uint32_t n_lights ) {
+    const float pick_pdf = light_pick_pdf( func_int, n_lights );
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if ( p >= pi.n_pixels ) return;
     V3 sum = mk3( 0.f );
     for ( uint32_t s = 0; s < pi.n_samples; s++ ) {
         const uint32_t id = pass_path( pi, s, p );
         V3 L              = mk3( ps.Lx[id], ps.Ly[id], ps.Lz[id] );
-        fold_pending( ps, id, L );
+        fold_pending( ps, id, L, pick_pdf );
         sum = sum + L;
     }
     uint32_t px, py;

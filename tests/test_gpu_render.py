@@ -414,7 +414,7 @@ def test_one_pass_of_half_a_billion_paths():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free_b = torch.cuda.mem_get_info()[0]
-    per_path = (50 + 4) * 4
+    per_path = (49 + 4) * 4
     cap = min(int(0.82 * free_b) // per_path, 1 << 30)
     want_passes = -(-spp // max(1, cap // (W * H)))
     assert W * H * spp > 1 << 29
