@@ -66,14 +66,31 @@ def own_bytes(ts, n):
 
 
 def profile_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/hbm_traffic.json),
-    with the L2 hit rate of the same run; (None, None) when the workload was not profiled."""
+    """From the committed counter passes (profiles/hbm_traffic.json): HBM bytes per launch of `kernel`, the
+    L2 hit rate of the same run, and the L2's read requests to the fabric per launch (one per missed line);
+    Nones when the workload was not profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             w = json.load(f)["workloads"][workload]
-        return w["bytes_per_launch"].get(kernel), w.get("tcc_hit_rate", {}).get(kernel)
+        n = w["dispatches_per_step"].get(kernel)
+        lines = w.get("fabric_read_requests_per_step", {}).get(kernel)
+        return w["bytes_per_launch"].get(kernel), w.get("tcc_hit_rate", {}).get(kernel), (lines / n if lines and n else None)
     except Exception:
-        return None, None
+        return None, None, None
+
+
+def line_fetch_ceiling():
+    """The rate at which this GPU delivers 128-byte lines to random 32-byte gathers that miss every cache
+    (raytracer_amd/gather_bench on a 4 GB table at the traversal kernels' 6 waves per SIMD), in G lines/s,
+    measured now in a child process; None when the binary is missing."""
+    exe = os.path.join(ROOT, "raytracer_amd", "gather_bench")
+    try:
+        out = subprocess.run([exe, "independent", "4096", "6", "32", "2000"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             text=True, timeout=120).stdout
+        row = [l for l in out.splitlines() if l.startswith("independent")][-1].split()
+        return float(row[9])  # mode, record, "B", table, "MB", waves, G records/s, ns per step, GB/s, G lines/s, ...
+    except Exception:
+        return None
 
 
 def measure(name, args, rank, world, dist, local_rank, with_cpu):
@@ -86,6 +103,7 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
     from raytracer_amd.host import DeviceScene, render_params
 
     wl = WORKLOADS[name]
+    line_ceiling = line_fetch_ceiling() if (rank == 0 and world == 1 and with_cpu) else None
     spp_x, spp_y = wl["spp"]
     if args.spp_y:
         spp_y = args.spp_y
@@ -189,6 +207,19 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
             proxy["n%d" % n_way] = {"spp": spp // n_way, "ms": p_elapsed / args.steps * 1e3,
                                     "efficiency": (elapsed / args.steps) / (n_way * p_elapsed / args.steps)}
         proxy["efficiency"] = proxy["n8"]["efficiency"]
+        # the other way to divide the frame: an interleaved share of its 8x8 tiles, all samples each (the sums of
+        # the shares are the frame, reduced the same way)
+        tiles = {}
+        for n_way in (2, 4, 8):
+            if not parallel.tile_share_possible(WIDTH, HEIGHT, n_way):
+                continue
+            pp = parallel.rank_params(WIDTH, HEIGHT, spp_x, spp_y, 0, n_way, max_depth=MAX_DEPTH, seed=SEED, split="tile")
+            timed(pp, 1)
+            p_elapsed, _, _, _, _ = timed(pp, args.steps)
+            tiles["n%d" % n_way] = {"ms": p_elapsed / args.steps * 1e3, "efficiency": (elapsed / args.steps) / (n_way * p_elapsed / args.steps)}
+        if tiles:
+            tiles["note"] = "share 0 of the tiles (tx + ty) mod N == 0, all %d samples of its pixels" % spp
+            proxy["tile_split"] = tiles
 
     if rank != 0:
         dev.close()
@@ -264,7 +295,7 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
         byts = bpr[cls] * step_rays * share[cls] / tot
         achieved = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         launches = (MAX_DEPTH + 1) * n_passes // args.steps
-        traffic, hit_rate = profile_traffic(name, kname) if (spp_x, spp_y) == wl["spp"] and world == 1 else (None, None)
+        traffic, hit_rate, miss_lines = profile_traffic(name, kname) if (spp_x, spp_y) == wl["spp"] and world == 1 else (None, None, None)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": kname if kname != "extend_kernel" else "extend_kernel (+ extend_camera_kernel, its first-bounce instance)",
                 "launches_per_step": launches,
@@ -273,14 +304,22 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
                 "bytes_per_ray": bpr, "reference_bytes_per_ray": ref_bytes_per_ray,
                 "timing": "kernel alone on the device (MRT_RENDER_SERIAL frame)",
                 "note": "achieved = ALGORITHMIC bytes (52 + 8*inner + 8*leaves + 4*refs + 36*prim_tests per ray, visits counted by the "
-                        "kernels themselves on an untimed pass) of the kernel's launches of one step / their summed HIP-event time: a "
-                        "gather rate, most of it served by L2 and the memory-side cache.  traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per "
-                        "launch from the committed counter passes (profiles/hbm_traffic.json); hbm_frac_from_counters = traffic / launch "
-                        "time / peak is the real HBM utilisation.  The counters say the loop is bound by L2 / memory-side-cache gather "
-                        "latency and look-up count, not by HBM bandwidth."}
+                        "kernels themselves on an untimed pass) of the kernel's launches of one step / their summed HIP-event time.  "
+                        "traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch from the committed counter passes (profiles/hbm_traffic.json; "
+                        "the doubling is calibrated for this access pattern, profiles/r03_gather_calibration.json); "
+                        "hbm_frac_from_counters = traffic / launch time / peak.  The traversal gathers 16 bytes at a time and every gather "
+                        "that misses the L2 moves a whole 128-byte line, so what bounds the kernel is the number of lines the fabric "
+                        "delivers per second, not their bytes: line_fetch."}
         if traffic and launches:
             roof["hbm_frac_from_counters"] = traffic / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS
-            roof["limiter"] = "L2 / memory-side-cache gather latency (TCC hit rate %.2f)" % hit_rate if hit_rate else "L2 gather latency"
+            roof["limiter"] = "fabric line fetches: one 128-byte line per L2 miss of a 16-byte gather" + (" (TCC hit rate %.2f)" % hit_rate if hit_rate else "")
+        if miss_lines and launches:
+            rate = miss_lines / (ms / launches * 1e-3) / 1e9
+            roof["line_fetch"] = {"lines_per_launch": miss_lines, "G_lines_per_s": rate, "ceiling_G_lines_per_s": line_ceiling,
+                                  "frac": rate / line_ceiling if line_ceiling else None,
+                                  "note": "lines = the L2's read requests to the fabric (TCC_EA0_RDREQ, committed counter pass); ceiling = "
+                                          "raytracer_amd/gather_bench measured in this run: random 32-byte gathers over a 4 GB table at 6 "
+                                          "waves per SIMD, every one a miss (the same rate whether 32, 64 or 128 bytes of the line are used)"}
     out["roofline"] = roof
     out["cpu_baseline"] = cpu
     dev.close()

@@ -205,6 +205,12 @@ typedef struct mrt_render_params {
     uint32_t row_begin, row_end;           /* scanlines rendered by this call (tile split) */
     uint32_t paths_per_pass;               /* 0 = library default; at most 2^30 (MRT_ERR_UNSUPPORTED beyond) */
     uint32_t flags;                        /* MRT_RENDER_* */
+    /* tile_step > 1: only the 8x8-pixel tiles (tx, ty) with (tx + ty) % tile_step == tile_phase are
+     * rendered (tiles counted from the image's top left corner) -- an interleaved share of the image for
+     * one of tile_step GPUs, all samples of its pixels; the shares of the tile_step phases tile the frame
+     * and every pixel's sum is the one a whole-frame call makes.  Needs width % (8 * tile_step) == 0 and
+     * row_begin, row_end (or height) multiples of 8 (MRT_ERR_UNSUPPORTED otherwise).  0 or 1: all tiles. */
+    uint32_t tile_step, tile_phase;
 } mrt_render_params;
 
 enum {
@@ -400,7 +406,8 @@ mrt_status mrt_debug_camera_choice( const mrt_scene* scene, int32_t* packets, fl
 
 const char* mrt_last_error( void );
 /* The version of this header the library was built from (MRT_VERSION).  2: mrt_render_stats ends
- * with `passes` (a caller built against version 1 must not pass its shorter struct), mrt_scene_trim,
+ * with `passes` and mrt_render_params with tile_step, tile_phase (a caller built against version 1 must not
+ * pass its shorter structs), mrt_scene_trim,
  * mrt_reduce_async, mrt_debug_relayed, mrt_debug_camera_choice. */
 #define MRT_VERSION 2
 int32_t mrt_version( void );

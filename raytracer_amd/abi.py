@@ -91,7 +91,8 @@ class TraceStats(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "spp_x", "spp_y", "sample_begin", "sample_end",
-                                          "max_depth", "seed", "row_begin", "row_end", "paths_per_pass", "flags")]
+                                          "max_depth", "seed", "row_begin", "row_end", "paths_per_pass", "flags",
+                                          "tile_step", "tile_phase")]
 
 
 class RenderStats(C.Structure):

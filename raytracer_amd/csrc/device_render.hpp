@@ -81,9 +81,13 @@ struct PassInfo {
     uint32_t sample_begin, n_samples;
     uint32_t spp_x, spp_y;
     uint32_t seed;
-    uint32_t n_pixels;               // n_rows * width
+    uint32_t n_pixels;               // n_rows * width / tile_step
     uint32_t n_paths;                // n_pixels * n_samples
     uint32_t max_depth;
+    // tile_step > 1: the pass holds only the 8x8 tiles (tx, ty) of its rows with (tx + ty) % tile_step ==
+    // tile_phase (ty counted from the top of the IMAGE); width is then a multiple of 8 * tile_step and the
+    // pass is made of whole tiles
+    uint32_t tile_step, tile_phase;
 };
 
 // A pass made of whole 8x8 pixel tiles numbers its pixels and paths tile by tile.
@@ -101,6 +105,17 @@ MRT_DEV bool pass_tiled( const PassInfo& pi ) {
 // queue's neighbours) cover a square of the image instead of a 64-pixel line: their rays start
 // closer together and walk more of the same subtrees.  Otherwise scanline order.
 MRT_DEV void pass_pixel( const PassInfo& pi, uint32_t p_local, uint32_t& x, uint32_t& y ) {
+    if ( pi.tile_step > 1u ) {
+        // a share of the tiles, row of tiles by row of tiles: every row holds width / 8 / tile_step of them,
+        // tile_step tiles apart, starting where (tx + ty) % tile_step == tile_phase
+        const uint32_t tile = p_local >> 6, in = p_local & 63u, per_row = ( pi.width >> 3 ) / pi.tile_step;
+        const uint32_t ty_local = tile / per_row, j = tile - ty_local * per_row;
+        const uint32_t ty = ( pi.row_begin >> 3 ) + ty_local;
+        const uint32_t tx = ( pi.tile_phase + pi.tile_step - ty % pi.tile_step ) % pi.tile_step + j * pi.tile_step;
+        x = ( tx << 3 ) + ( in & 7u );
+        y = ( ty << 3 ) + ( in >> 3 );
+        return;
+    }
     if ( pass_tiled( pi ) ) {
         const uint32_t tile = p_local >> 6, in = p_local & 63u, tiles_x = pi.width >> 3;
         uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;

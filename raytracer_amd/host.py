@@ -395,7 +395,7 @@ class DeviceScene:
 
 
 def render_params(width, height, spp_x, spp_y, max_depth=5, seed=1, sample_begin=0, sample_end=None, row_begin=0,
-                  row_end=None, paths_per_pass=0, flags=0):
+                  row_end=None, paths_per_pass=0, flags=0, tile_step=0, tile_phase=0):
     p = abi.RenderParams()
     p.width, p.height, p.spp_x, p.spp_y = width, height, spp_x, spp_y
     p.sample_begin = sample_begin
@@ -405,4 +405,5 @@ def render_params(width, height, spp_x, spp_y, max_depth=5, seed=1, sample_begin
     p.row_end = height if row_end is None else row_end
     p.paths_per_pass = paths_per_pass
     p.flags = flags
+    p.tile_step, p.tile_phase = tile_step, tile_phase
     return p

@@ -906,3 +906,52 @@ def test_reduce_without_host_synchronisation():
     assert np.allclose(got, want, rtol=1e-5, atol=1e-6) and want.max() > 0
     for d in devs:
         d.close()
+
+
+@pytest.mark.parametrize("step", [2, 4])
+def test_tile_shares_tile_the_frame(step):
+    """mrt_render with tile_step / tile_phase (the strong-scaling tile split): the shares of all phases,
+    each rendered into a zeroed image and added, are the whole-frame call's image bit for bit (single
+    pass each: a pixel's samples are summed in one go either way), every share leaves the other shares'
+    pixels at zero, the rays add up, passes of a share are cut by rows of tiles, and the parameters that
+    cannot be honoured are refused."""
+    import ctypes as C
+    import torch
+    W, H = 64 * step // 2 * 2, 48
+    sc = scenes.small_bunny(W, H, env_pixels=scenes.synthetic_env())
+    flat = sc.initKdTree().flatten(1)
+    dev = DeviceScene(flat)
+    full = torch.zeros((H, W, 3), device="cuda")
+    rs = dev.render(render_params(W, H, 4, 4, max_depth=4, seed=8), full)
+    total = torch.zeros_like(full)
+    rays = 0
+    for phase in range(step):
+        img = torch.zeros_like(full)
+        r = dev.render(render_params(W, H, 4, 4, max_depth=4, seed=8, tile_step=step, tile_phase=phase), img)
+        rays += r.rays_closest + r.rays_any
+        assert r.paths == W * H * 16 // step
+        ty, tx = torch.meshgrid(torch.arange(H, device="cuda") // 8, torch.arange(W, device="cuda") // 8, indexing="ij")
+        mine = ((tx + ty) % step == phase)
+        assert not img[~mine].any() and img[mine].any()
+        total += img
+    torch.cuda.synchronize()
+    assert torch.equal(total, full) and rays == rs.rays_closest + rs.rays_any
+    # several passes per share (rows of tiles, then samples), and a share of a row range
+    img = torch.zeros_like(full)
+    r = dev.render(render_params(W, H, 4, 4, max_depth=4, seed=8, tile_step=step, tile_phase=1, paths_per_pass=W // step * 8 * 5), img)
+    part = torch.zeros_like(full)
+    dev.render(render_params(W, H, 4, 4, max_depth=4, seed=8, tile_step=step, tile_phase=1), part)
+    torch.cuda.synchronize()
+    # room for 40 scanlines of the share at one sample: 40 + 8 rows, 16 sample passes each
+    assert r.passes == 2 * 16 and torch.allclose(img, part, rtol=1e-5, atol=1e-6)
+    band = torch.zeros_like(full)
+    dev.render(render_params(W, H, 4, 4, max_depth=4, seed=8, tile_step=step, tile_phase=1, row_begin=16, row_end=32), band)
+    torch.cuda.synchronize()
+    assert torch.equal(band[16:32], part[16:32]) and not band[:16].any() and not band[32:].any()
+    lib = abi.hip()
+    host = np.zeros((H, W, 3), np.float32)
+    for kw, st in [(dict(tile_step=step, tile_phase=step), 1), (dict(tile_step=step, tile_phase=0, row_begin=4), 4),
+                   (dict(tile_step=7, tile_phase=0), 4)]:
+        p = render_params(W, H, 2, 2, **kw)
+        assert lib.mrt_render(dev._h, C.byref(p), host.ctypes.data_as(C.c_void_p), abi.MRT_BUF_HOST, None, None) == st, kw
+    dev.close()

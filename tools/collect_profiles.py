@@ -46,7 +46,8 @@ if os.path.exists(path):
     except Exception:
         pass
 w = {"tag": tag, "bytes_per_launch": {}, "bytes_per_step": {}, "fetch_size_kib_per_step": {}, "write_size_kib_per_step": {},
-     "dispatches_per_step": {}, "tcc_hit_rate": {}}
+     "dispatches_per_step": {}, "tcc_hit_rate": {}, "l2_requests_per_step": {}, "l2_misses_per_step": {},
+     "fabric_read_requests_per_step": {}, "fabric_read_bytes_per_step": {}, "l1_to_l2_read_requests_per_step": {}}
 for k, c in pmc.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
@@ -58,6 +59,14 @@ for k, c in pmc.items():
     w["write_size_kib_per_step"][k] = c["WRITE_SIZE"]
     if c.get("TCC_REQ_sum"):
         w["tcc_hit_rate"][k] = c["TCC_HIT_sum"] / c["TCC_REQ_sum"]
+        w["l2_requests_per_step"][k] = c["TCC_REQ_sum"]
+        w["l2_misses_per_step"][k] = c["TCC_MISS_sum"]
+    if c.get("TCC_EA0_RDREQ_sum"):
+        # the L2's read requests to the fabric, and their bytes by request size
+        w["fabric_read_requests_per_step"][k] = c["TCC_EA0_RDREQ_sum"]
+        w["fabric_read_bytes_per_step"][k] = 32.0 * c.get("TCC_EA0_RDREQ_32B_sum", 0) + 64.0 * c.get("TCC_EA0_RDREQ_64B_sum", 0) + 128.0 * c.get("TCC_EA0_RDREQ_128B_sum", 0)
+    if c.get("TCP_TCC_READ_REQ_sum"):
+        w["l1_to_l2_read_requests_per_step"][k] = c["TCP_TCC_READ_REQ_sum"]
 allw["workloads"][workload] = w
 with open(path, "w") as f:
     json.dump(allw, f, indent=1)
@@ -71,7 +80,7 @@ if kernel in w["bytes_per_launch"] and roof.get("avg_launch_ms"):
     roof["traffic"] = w["bytes_per_launch"][kernel]
     roof["hbm_frac_from_counters"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / roof["peak"]
     if kernel in w["tcc_hit_rate"]:
-        roof["limiter"] = "L2 / memory-side-cache gather latency (TCC hit rate %.2f)" % w["tcc_hit_rate"][kernel]
+        roof["limiter"] = "fabric line fetches: every L2 miss of a 16-byte gather moves a 128-byte line (TCC hit rate %.2f)" % w["tcc_hit_rate"][kernel]
     with open(bench_path, "w") as f:
         f.write(json.dumps(line) + "\n")
 print("profiles written for", tag, workload)

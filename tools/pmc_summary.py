@@ -13,7 +13,9 @@ from collections import defaultdict
 
 def short(name):
     name = name.split("(")[0]
-    if "extend_camera_kernel" in name:  # the first-bounce instance of the extend traversal
+    if "relay_trace_kernel" in name or "relay_finish_kernel" in name:  # the follow-up launches of the long rays
+        return "relay_kernels"
+    if "extend_camera" in name:  # the first-bounce instances of the extend traversal (streaming or packets)
         return "extend_kernel"
     for k in ("extend_batch_kernel", "extend_kernel", "connect_shadow_kernel", "connect_mis_occlusion_kernel", "connect_mis_kernel", "mis_resolve_kernel", "shade_kernel",
               "generate_kernel", "accumulate_kernel", "resolve_kernel"):
