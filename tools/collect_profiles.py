@@ -24,7 +24,9 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 base = "%s_%s" % (tag, workload)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+# (the bench also runs raytracer_amd/gather_bench as a child process, which the profiler traces as well: the
+# file wanted is the one with the renderer's kernels)
+stats = [f for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")) if "extend_kernel" in open(f).read()][0]
 shutil.copy(stats, os.path.join(dst, base + "_kernel_stats.csv"))
 line = [l for l in open(os.path.join(src, "bench.log")) if l.startswith('{"metric"')][-1]
 with open(os.path.join(dst, base + "_bench.json"), "w") as f:
