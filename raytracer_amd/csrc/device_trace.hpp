@@ -75,8 +75,11 @@ struct RefillMin {
 //        even depth), left child w0, left child w1
 //   q1 = right child w0, right child w1, first reference of the left child, of the right child
 // A child is an inner node (split bits, axis | record << 2: `record` holds its left child and
-// record + 1 its right child) or a leaf (first reference, 3 | count << 2); a leaf's first reference
-// arrives with the record, the further ones come from the reference list one trip ahead.
+// record + 1 its right child) or a leaf (w0, 3 | count << 2); a leaf's first reference
+// arrives with the record, the further ones come from the reference list one trip ahead: words
+// w0 + 1 .. w0 + count - 1 of DTrace::refs.  By default the lists live in the same pool of 32-byte
+// slots as the records, each right behind the pair of sibling records that holds its leaf
+// (build_tree_records), so refs points at the pool and record numbers count list slots too.
 #ifndef MRT_PRIM_Q
 #define MRT_PRIM_Q 4 // float4 per primitive record: three used, padded to one 64-byte line
 #endif
@@ -93,12 +96,12 @@ struct RefillMin {
 
 struct DTrace {
     const uint4* nodes; // two uint4 per record
-    const uint32_t* refs;
+    const uint32_t* refs; // the leaves' lists: the pool of records itself, or an array of their own
     const float4* prims;
     const DXf* xforms;
     const uint32_t* out_of_tree;
     uint32_t n_nodes;
-    uint32_t n_records; // 32-byte records in `nodes` (at least 1 when n_nodes != 0)
+    uint32_t n_records; // 32-byte slots in `nodes` (at least 1 when n_nodes != 0)
     uint32_t n_out;
     uint32_t n_xforms;
     float root_min[3];

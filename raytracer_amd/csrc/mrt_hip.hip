@@ -278,37 +278,96 @@ mrt_status validate_tree( const mrt_scene_desc* d, uint32_t* depth_out, std::vec
 // The tree as the kernels read it: one 32-byte record (two uint4) per node of even depth, holding
 // the node and its two children (layout in device_trace.hpp); records follow the order of the
 // caller's nodes.  Expects the depth parities validate_tree made of a tree that passed it.
-mrt_status build_tree_records( const mrt_scene_desc* d, const std::vector<uint8_t>& level, HostBuf<uint4>& nodes ) {
+//
+// With `inline_lists` the records and the leaves' reference lists share one pool of 32-byte slots: the
+// two records of a sibling pair are followed by the lists of the (up to four) leaves they hold -- every
+// reference but a leaf's first, which rides in the record -- padded to a whole slot, then by the pair's
+// subtrees.  A ray that has just fetched a record finds the list of the leaf it enters in the same or the
+// next cache line instead of somewhere in a separate array of 4-byte indices that is as large as the tree.
+// A leaf's w0 is then the pool word before its list (the kernels read words w0 + 1 .. w0 + count - 1 of
+// DTrace::refs, which points at the pool), and DTrace::n_records counts records and list slots together.
+mrt_status build_tree_records( const mrt_scene_desc* d, const std::vector<uint8_t>& level, bool inline_lists, bool align_groups, HostBuf<uint4>& nodes ) {
     nodes = HostBuf<uint4>();
     if ( d->n_nodes ) {
-        HostBuf<uint32_t> record( d->n_nodes ); // defined for the nodes of even depth
-        uint32_t n_records = 0;
-        for ( uint32_t i = 0; i < d->n_nodes; i++ )
-            if ( level[i] == 0 ) record[i] = n_records++;
-        // a child as the traversal reads it: (w0, w1, first reference)
-        auto child = [&]( uint32_t n, uint32_t out[3] ) {
+        HostBuf<uint32_t> record( d->n_nodes ); // the slot of the record of a node of even depth
+        HostBuf<uint32_t> list_at;              // inline_lists: the pool word where the lists of that record's leaves start
+        uint64_t n_slots = 0;
+        // words the lists of the leaves held by the record of even-depth node i take
+        auto list_words = [&]( uint32_t i ) {
+            auto of_leaf = [&]( uint32_t n ) {
+                const uint32_t w1 = d->nodes[n].w1;
+                return ( w1 & 3u ) == 3u && ( w1 >> 2 ) > 1u ? (uint64_t)( w1 >> 2 ) - 1u : (uint64_t)0;
+            };
+            const uint32_t w1 = d->nodes[i].w1;
+            if ( ( w1 & 3u ) == 3u ) return of_leaf( i );
+            return of_leaf( w1 >> 2 ) + of_leaf( ( w1 >> 2 ) + 1u );
+        };
+        if ( !inline_lists ) {
+            for ( uint32_t i = 0; i < d->n_nodes; i++ )
+                if ( level[i] == 0 ) record[i] = (uint32_t)n_slots++;
+        }
+        else {
+            list_at = HostBuf<uint32_t>( d->n_nodes );
+            std::vector<uint8_t> first( d->n_nodes, 0 ); // the left one of a sibling pair of even depth
+            first[0] = 1;
+            parallel_ranges( d->n_nodes, [&]( size_t begin, size_t end ) {
+                for ( size_t i = begin; i < end; i++ )
+                    if ( level[i] == 1 && ( d->nodes[i].w1 & 3u ) != 3u ) first[d->nodes[i].w1 >> 2] = 1;
+            } );
+            for ( uint32_t i = 0; i < d->n_nodes; i++ ) {
+                if ( level[i] != 0 || !first[i] ) continue;
+                const bool pair = i != 0;
+                if ( align_groups ) {
+                    // a pair and its lists that fit one 128-byte line do not straddle two
+                    const uint64_t group = ( pair ? 2u : 1u ) + ( list_words( i ) + ( pair ? list_words( i + 1 ) : 0u ) + 7u ) / 8u;
+                    if ( group <= 4u && ( n_slots & 3u ) + group > 4u ) n_slots = ( n_slots + 3u ) & ~(uint64_t)3u;
+                }
+                record[i]       = (uint32_t)n_slots++;
+                if ( pair ) record[i + 1] = (uint32_t)n_slots++;
+                uint64_t words = n_slots * 8u;
+                list_at[i]     = (uint32_t)words;
+                words += list_words( i );
+                if ( pair ) {
+                    list_at[i + 1] = (uint32_t)words;
+                    words += list_words( i + 1 );
+                }
+                n_slots = ( words + 7u ) / 8u;
+                if ( n_slots >= ( 1u << 27 ) ) break;
+            }
+        }
+        // a child as the traversal reads it: (w0, w1, first reference); `at`: where its list goes
+        auto child = [&]( uint32_t n, uint32_t out[3], uint32_t& at ) {
             const uint32_t w0 = d->nodes[n].w0, w1 = d->nodes[n].w1;
             out[0] = w0, out[1] = w1, out[2] = 0;
             if ( ( w1 & 3u ) == 3u ) {
-                if ( ( w1 >> 2 ) > 0 ) out[2] = d->refs[w0];
+                const uint32_t cnt = w1 >> 2;
+                if ( cnt > 0 ) out[2] = d->refs[w0];
+                if ( inline_lists ) {
+                    out[0] = cnt > 1 ? at - 1u : 0u;
+                    uint32_t* pool = (uint32_t*)nodes.p;
+                    for ( uint32_t k = 1; k < cnt; k++ )
+                        pool[at++] = d->refs[w0 + k];
+                }
             }
             else out[1] = ( w1 & 3u ) | ( record[w1 >> 2] << 2 ); // its children are adjacent nodes of even depth: adjacent records
         };
-        // the kernels form a record's byte offset (record << 5) in 32 bits
-        if ( n_records >= ( 1u << 27 ) ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree too large (limit: 2^27 nodes of even depth)" );
-        nodes = HostBuf<uint4>( 2 * (size_t)n_records );
-        // every record is written by the one thread whose range holds its node
+        // the kernels form a slot's byte offset (slot << 5) in 32 bits
+        if ( n_slots >= ( 1u << 27 ) ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree too large (limit: 2^27 nodes of even depth, 4 GB of records and reference lists)" );
+        nodes = HostBuf<uint4>( 2 * (size_t)n_slots );
+        if ( inline_lists ) std::memset( nodes.p, 0, 2 * (size_t)n_slots * sizeof( uint4 ) ); // the padding
+        // every record (and its lists) is written by the one thread whose range holds its node
         parallel_ranges( d->n_nodes, [&]( size_t begin, size_t end ) {
             for ( size_t i = begin; i < end; i++ ) {
                 if ( level[i] != 0 ) continue;
                 const uint32_t w0 = d->nodes[i].w0, w1 = d->nodes[i].w1;
                 uint32_t l[3] = { 0, 0, 0 }, r[3] = { 0, 0, 0 };
                 uint32_t h0 = 0, h1 = 3;
-                if ( ( w1 & 3u ) == 3u ) child( (uint32_t)i, l ); // a leaf of even depth: no head step
+                uint32_t at = inline_lists ? list_at[i] : 0u;
+                if ( ( w1 & 3u ) == 3u ) child( (uint32_t)i, l, at ); // a leaf of even depth: no head step
                 else {
                     h0 = w0, h1 = w1 & 3u;
-                    child( w1 >> 2, l );
-                    child( ( w1 >> 2 ) + 1, r );
+                    child( w1 >> 2, l, at );
+                    child( ( w1 >> 2 ) + 1, r, at );
                 }
                 nodes[2 * (size_t)record[i]]     = make_uint4( h0, h1, l[0], l[1] );
                 nodes[2 * (size_t)record[i] + 1] = make_uint4( r[0], r[1], l[2], r[2] );
@@ -519,8 +578,16 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
     reordered.refs = r_refs.p, reordered.out_of_tree = r_out.p;
     d = &reordered;
 
+    // MRT_REFS_INLINE=0 keeps the leaves' reference lists in an array of their own (measurements)
+#if MRT_TOP_LDS
+    const bool inline_lists = false; // (the staged top of the tree is addressed by record number)
+#else
+    const char* inl         = std::getenv( "MRT_REFS_INLINE" );
+    const bool inline_lists = !( inl && std::strcmp( inl, "0" ) == 0 );
+#endif
+    const bool align_groups = inl && std::strcmp( inl, "2" ) == 0;
     HostBuf<uint4> nodes;
-    vs = build_tree_records( d, level, nodes );
+    vs = build_tree_records( d, level, inline_lists, align_groups, nodes );
     if ( vs != MRT_OK ) return vs;
     level = std::vector<uint8_t>();
 
@@ -583,7 +650,7 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
     s->no_emitters = no_emitters;
     s->mixed_kinds = ( kinds_seen & ( kinds_seen - 1u ) ) != 0u;
     HIP_TRY( s->nodes.upload( nodes.p, nodes.n ) );
-    HIP_TRY( s->refs.upload( d->refs, d->n_refs ) );
+    if ( !inline_lists ) HIP_TRY( s->refs.upload( d->refs, d->n_refs ) );
     HIP_TRY( s->prims.upload( prims ) );
     HIP_TRY( s->xforms.upload( xforms ) );
     HIP_TRY( s->out_of_tree.upload( d->out_of_tree, d->n_out_of_tree ) );
@@ -625,7 +692,7 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
 
     DTrace& t     = s->trace;
     t.nodes       = s->nodes.p;
-    t.refs        = s->refs.p;
+    t.refs        = inline_lists ? (const uint32_t*)s->nodes.p : s->refs.p;
     t.prims       = s->prims.p;
     t.xforms      = s->xforms.p;
     t.out_of_tree = s->out_of_tree.p;

@@ -433,6 +433,49 @@ def test_object_order_inside_the_library_is_invisible(built, monkeypatch):
     assert np.array_equal(out[0][1], out[1][1]) and out[0][1].max() > 0
 
 
+@pytest.mark.parametrize("name", ["cornell", "bunny_plane", "transforms", "fuzz3", "fuzz6"])
+def test_where_the_leaf_lists_live_is_invisible(built, monkeypatch, name):
+    """The leaves' reference lists inside the pool of tree records right behind the pair of records that
+    holds them (the default), the same with groups that fit a cache line kept from straddling two
+    (MRT_REFS_INLINE=2), or in an array of their own (=0): hits equal the oracle's, every output array
+    and the traversal counters are the same bits in all three, both node layouts, packets included."""
+    from tests import fuzz_scenes
+    if name == "cornell":
+        sc = scenes.cornell(96, 96)
+    elif name == "bunny_plane":
+        sc = scenes.small_bunny(96, 96, env_pixels=scenes.synthetic_env())
+    elif name == "transforms":
+        sc = _many_transform_scene()
+    else:
+        sc = fuzz_scenes.make(int(name[4:]))  # leaves of one, many and no primitives, ties
+    tree = sc.initKdTree(2 if name.startswith("fuzz") else 16)
+    for layout in (0, 1):
+        flat = tree.flatten(layout)
+        o, d, tmin, tmax = _rays(flat, 96, 96, 20000, 5)
+        out = []
+        for mode in (None, "0", "2"):
+            if mode is None:
+                monkeypatch.delenv("MRT_REFS_INLINE", raising=False)
+            else:
+                monkeypatch.setenv("MRT_REFS_INLINE", mode)
+            dev = DeviceScene(flat)
+            for any_hit in (False, True):
+                assert _compare(flat, dev, o, d, tmin, tmax, any_hit) > 1000
+            res = dev.intersect(o, d, tmin, tmax, stats=True)
+            monkeypatch.setenv("MRT_INTERSECT_PACKETS", "1")
+            pk = DeviceScene(flat)
+            monkeypatch.delenv("MRT_INTERSECT_PACKETS")
+            res_pk = pk.intersect(o, d, tmin, tmax)
+            pk.close()
+            dev.close()
+            gs = res[4]
+            out.append((res[:4], (gs.inner, gs.leaves, gs.refs, gs.prim_tests), res_pk))
+        for other in out[1:]:
+            assert other[1] == out[0][1]
+            for a, b in zip(out[0][0] + out[0][2], other[0] + other[2]):
+                assert np.array_equal(_bits(a) if a.dtype == np.float32 else a, _bits(b) if b.dtype == np.float32 else b)
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_random_scenes_with_ties_against_the_oracle(built, seed):
     """Differential test on seeded random scenes built to produce ties (tests/fuzz_scenes.py):
