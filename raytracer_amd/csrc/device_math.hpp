@@ -37,8 +37,11 @@ MRT_DEV V3 mk3( float a, float b, float c ) {
 MRT_DEV V3 mk3( float a ) {
     return mk3( a, a, a );
 }
-MRT_DEV float comp( const V3& v, int i ) {
-    return i == 0 ? v.x : ( i == 1 ? v.y : v.z );
+MRT_DEV float comp( V3 v, int i ) {
+    // all three components are read before the choice, so the choice is two selects and not a branch
+    const float x = v.x, y = v.y, z = v.z;
+    const float yz = i == 1 ? y : z;
+    return i == 0 ? x : yz;
 }
 MRT_DEV V3 operator+( V3 a, V3 b ) {
     return mk3( a.x + b.x, a.y + b.y, a.z + b.z );

@@ -335,7 +335,7 @@ MRT_DEV bool bucket_by_kind( const DTrace& tr, const PathState& ps, uint32_t& id
         const uint32_t bits = __float_as_uint( ps.hit[id].x );
         if ( bits == 0xffffffffu ) kind = 0u;
         else {
-            const uint32_t flags = __float_as_uint( tr.prims[MRT_PRIM_Q * (size_t)( bits & 0x7fffffffu )].w );
+            const uint32_t flags = tr.prim_info[bits & 0x7fffffffu].x;
             kind                 = 1u + ( ( flags >> MRT_PRIM_SHADE_SHIFT ) & 3u );
             if ( kind > 3u ) kind = 3u;
         }
@@ -686,7 +686,7 @@ __global__ void __launch_bounds__( 256 ) mis_resolve_kernel( DTrace tr, DShade s
         const uint32_t li = ps.mlight[id];
         V3 Li             = mk3( 0.f );
         if ( h.prim >= 0 ) { // integrator.cpp:108-113
-            const uint32_t flags = __float_as_uint( tr.prims[MRT_PRIM_Q * (size_t)h.prim].w );
+            const uint32_t flags = tr.prim_info[h.prim].x;
             if ( flags & MRT_PRIM_EMISSIVE_SUM ) {
                 Surf sf = surface_from_hit( tr, sh, o, d, h );
                 // `wi` of the reference is the un-normalised sample direction; the ray direction is

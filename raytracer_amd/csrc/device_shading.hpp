@@ -532,13 +532,12 @@ MRT_DEV void camera_ray( const DCamera& cam, float sx, float sy, float uLens, fl
 // (triangle.cpp:36-49, sphere.cpp:134-158, plane.cpp:32-43) from (prim, t, barycentrics).
 MRT_DEV Surf surface_from_hit( const DTrace& tr, const DShade& s, V3 o, V3 d, const DHit& h ) {
     Surf sf;
-    const float4 q0      = tr.prims[MRT_PRIM_Q * (size_t)h.prim];
-    const float4 q2      = tr.prims[MRT_PRIM_Q * (size_t)h.prim + 2];
-    const uint32_t flags = __float_as_uint( q0.w );
+    const uint2 info     = tr.prim_info[h.prim];
+    const uint32_t flags = info.x;
     const uint32_t kind  = flags & 3u;
     const uint32_t xfi   = flags >> MRT_PRIM_XF_SHIFT;
     const DXf& xf        = tr.xforms[xfi];
-    sf.material          = __float_as_uint( q2.z );
+    sf.material          = info.y;
     sf.outside           = h.outside != 0;
     sf.position          = o + ( h.t * d );
     if ( kind == MRT_PRIM_TRI ) {

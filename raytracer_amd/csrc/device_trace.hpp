@@ -63,12 +63,17 @@ struct RefillMin {
     static constexpr uint32_t value = MRT_REFILL_MIN;
 };
 
-// prim record: 3 x float4 in a 64-byte slot (a record never straddles two cache lines)
-//   q0 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane),
-//   q1 = e1.xyz , e2.x              bit 2 emission != (0,0,0) component-wise (kdtree.cpp:533-534),
-//   q2 = e2.yz  , material , 0      bit 3 emission.r+g+b != 0 (isBlack, integrator.cpp:110),
-//                                   bits 4-5 shade kind of the object's material, bits 6.. transform index (0 = identity)
+// prim record: ten words, three records to a 128-byte line (slots at bytes 0, 40, 80; a record never
+// straddles two cache lines, and a line fetched for one primitive of a leaf brings two neighbours):
+//   words 0-3 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane),
+//   words 4-7 = e1.xyz , e2.x              bit 2 emission != (0,0,0) component-wise (kdtree.cpp:533-534),
+//   words 8-9 = e2.yz                      bit 3 emission.r+g+b != 0 (isBlack, integrator.cpp:110),
+//                                          bits 4-5 shade kind of the object's material, bits 6.. transform index (0 = identity)
 //   e1 = p2 - p1, e2 = p3 - p1 (fp32, as triangle.cpp:9-10)
+// The traversal names a primitive by where its record lies: line << 2 | slot (prim_loc); that is what
+// the tree records and the leaves' lists carry, and a ray's hit is turned back into the object index
+// when the ray retires.  (MRT_PRIM_PACK 0: 64-byte slots, two to a line, named by the index itself.)
+// What shading needs of an object -- (flags, material) -- lives in DTrace::prim_info.
 // Device tree: 32-byte records, one per node of even depth (the root has depth 0), holding that
 // node and its two children, so one fetch serves two levels of the descent:
 //   q0 = head split bits, head axis (0..2; 3 = no head step, the left slot IS the node: a leaf of
@@ -80,8 +85,8 @@ struct RefillMin {
 // w0 + 1 .. w0 + count - 1 of DTrace::refs.  By default the lists live in the same pool of 32-byte
 // slots as the records, each right behind the pair of sibling records that holds its leaf
 // (build_tree_records), so refs points at the pool and record numbers count list slots too.
-#ifndef MRT_PRIM_Q
-#define MRT_PRIM_Q 4 // float4 per primitive record: three used, padded to one 64-byte line
+#ifndef MRT_PRIM_PACK
+#define MRT_PRIM_PACK 1
 #endif
 #define MRT_PRIM_TRI 0u
 #define MRT_PRIM_SPHERE 1u
@@ -97,7 +102,8 @@ struct RefillMin {
 struct DTrace {
     const uint4* nodes; // two uint4 per record
     const uint32_t* refs; // the leaves' lists: the pool of records itself, or an array of their own
-    const float4* prims;
+    const float4* prims;     // the records the traversal reads (layout above)
+    const uint2* prim_info;  // per object: (flags, material)
     const DXf* xforms;
     const uint32_t* out_of_tree;
     uint32_t n_nodes;
@@ -313,8 +319,42 @@ MRT_DEV float4 ld_node( const DTrace& s, uint32_t rec, uint32_t half ) {
 MRT_DEV uint32_t ld_ref( const DTrace& s, uint32_t i ) {
     return *(const uint32_t*)( (const char*)s.refs + ( i << 2 ) );
 }
-MRT_DEV float4 ld_prim( const DTrace& s, uint32_t obj, uint32_t k ) {
-    return *(const float4*)( (const char*)s.prims + ( obj * ( MRT_PRIM_Q * 16u ) + k * 16u ) );
+// four consecutive references with one load instruction (the lists are word-aligned; what lies behind a
+// list's end -- the next list, padding -- is read and not used: the tables end with 16 spare bytes)
+typedef uint32_t v4u_a4 __attribute__( ( ext_vector_type( 4 ), aligned( 4 ) ) );
+MRT_DEV v4u_a4 ld_ref4( const DTrace& s, uint32_t i ) {
+    return *(const v4u_a4*)( (const char*)s.refs + ( i << 2 ) );
+}
+// primitive records: where the record of object `idx` lies, and back
+#define MRT_HD __host__ __device__ __forceinline__
+MRT_HD uint32_t prim_loc( uint32_t idx ) {
+#if MRT_PRIM_PACK
+    return ( ( idx / 3u ) << 2 ) | ( idx % 3u );
+#else
+    return idx;
+#endif
+}
+MRT_HD uint32_t prim_index( uint32_t loc ) {
+#if MRT_PRIM_PACK
+    return ( loc >> 2 ) * 3u + ( loc & 3u );
+#else
+    return loc;
+#endif
+}
+MRT_HD uint32_t prim_offset( uint32_t loc ) { // in bytes
+#if MRT_PRIM_PACK
+    return ( ( loc >> 2 ) << 7 ) + ( loc & 3u ) * 40u;
+#else
+    return loc << 6;
+#endif
+}
+typedef float4 float4_a8 __attribute__( ( aligned( 8 ) ) );
+// the first two quarters of a record (k = 0, 1) and its last two words
+MRT_DEV float4 ld_prim( const DTrace& s, uint32_t loc, uint32_t k ) {
+    return *(const float4_a8*)( (const char*)s.prims + ( prim_offset( loc ) + k * 16u ) );
+}
+MRT_DEV float2 ld_prim_tail( const DTrace& s, uint32_t loc ) {
+    return *(const float2*)( (const char*)s.prims + ( prim_offset( loc ) + 32u ) );
 }
 
 // The out-of-tree planes of a ray (kdtree.cpp:563-611), tested when the ray is fetched: an any-hit ray
@@ -330,7 +370,7 @@ MRT_DEV bool scan_planes( const DTrace& s, const lds_f32* xf_lds, V3 o, V3 d, fl
     rec         = mk4( 0.f, 0.f, 0.f, 0.f );
     for ( uint32_t k = 0; k < s.n_out; k++ ) {
         const uint32_t po = s.out_of_tree[k];
-        const uint32_t xf = __float_as_uint( ld_prim( s, po, 0 ).w ) >> MRT_PRIM_XF_SHIFT;
+        const uint32_t xf = s.prim_info[po].x >> MRT_PRIM_XF_SHIFT;
         V3 oo = o, od = d;
         if ( xf != 0 ) transform_ray( s, xf_lds, xf, o, d, oo, od );
         float t, u, v;
@@ -454,7 +494,10 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     // record in state TEST.
     float4 L0 = make_float4( 0.f, 0.f, 0.f, 0.f ), L1 = L0;
     float2 L2 = make_float2( 0.f, 0.f );
-    uint32_t ptr = 0, end = 0, obj = 0, next = 0;
+    uint32_t ptr = 0, end = 0, obj = 0;
+    // the references that follow in the current leaf's list, fetched four at a time: nq0 is the one at
+    // position ptr when a record goes in flight, and the queue covers positions [ptr, qhi)
+    uint32_t nq0 = 0, nq1 = 0, nq2 = 0, nq3 = 0, qhi = 0;
     uint32_t cur  = 0; // the record in L0, L1
     uint32_t pick = 0; // after a pop: 2 = resume at the left child of the record, 3 = at the right one
     uint32_t xr_id = 0;    // transform of the object-space ray in LDS
@@ -532,7 +575,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                     if ( STATS ) pl_tests = s.n_out;
                     for ( uint32_t k = 0; k < s.n_out; k++ ) {
                         const uint32_t po = s.out_of_tree[k];
-                        const uint32_t xf = __float_as_uint( ld_prim( s, po, 0 ).w ) >> MRT_PRIM_XF_SHIFT;
+                        const uint32_t xf = s.prim_info[po].x >> MRT_PRIM_XF_SHIFT;
                         V3 oo = o, od = d;
                         if ( xf != 0 ) transform_ray( s, xf_lds, xf, o, d, oo, od );
                         float t, u, v;
@@ -641,7 +684,8 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             end  = at_leaf ? w0 + ( w1 >> 2 ) : end;
             pop       = at_leaf & ( ptr == end );
             advance   = at_leaf & ( ptr != end ); // the first record goes in flight in this trip
-            next      = at_leaf ? r0 : next;
+            nq0       = at_leaf ? r0 : nq0;
+            qhi       = at_leaf ? w0 + 1u : qhi;
             if ( STATS ) {
                 st.inner += ( at_head ? 1u : 0u ) + ( at_node ? 1u : 0u );
                 st.leaves += at_leaf ? 1u : 0u;
@@ -731,7 +775,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             bool found = has;
             if ( !BOOL_ONLY ) {
                 const v2f rec = *out_lds;
-                h.prim    = has ? (int32_t)( __float_as_uint( rec.x ) & 0x7fffffffu ) : -1;
+                h.prim    = has ? (int32_t)prim_index( __float_as_uint( rec.x ) & 0x7fffffffu ) : -1;
                 h.t       = has ? tmax : rec.y;
                 h.u       = has ? rec.y : 0.f;
                 h.v       = has ? *outv_lds : 0.f;
@@ -754,14 +798,25 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
 #endif
         }
         // ---------------------------------------------------------------- issue
+        // (Two blocks, and between them the compiler makes the wave wait for the first block's data,
+        // because the second block's addresses share registers with what those loads are to deliver and it
+        // cannot know that the blocks serve different lanes.  Fetching both kinds of record with one pair
+        // of instructions from one base removes that wait -- and made the connection kernels 9 % slower:
+        // with six waves per SIMD the memory system is oversubscribed, and the wait spaces the requests.)
         if ( advance ) {
-            // the record of the next primitive and the reference after it go in flight
-            obj   = next;
+            // the record of the next primitive goes in flight, and the next four references when the
+            // queue has run out (one cache look-up per four primitives instead of one per primitive: the
+            // loop's pace follows the number of look-ups)
+            obj   = nq0;
             L0    = ld_prim( s, obj, 0 );
             L1    = ld_prim( s, obj, 1 );
-            const float4 r2 = ld_prim( s, obj, 2 );
-            L2    = make_float2( r2.x, r2.y );
-            if ( ptr + 1 < end ) next = ld_ref( s, ptr + 1 );
+            L2    = ld_prim_tail( s, obj );
+            nq0 = nq1, nq1 = nq2, nq2 = nq3;
+            if ( ptr + 1 >= qhi && ptr + 1 < end ) {
+                const v4u_a4 r = ld_ref4( s, ptr + 1 );
+                nq0 = r.x, nq1 = r.y, nq2 = r.z, nq3 = r.w;
+                qhi = ptr + 5u;
+            }
         }
         if ( want_node ) {
             cur = node;
@@ -818,6 +873,10 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
 typedef uint32_t v4u __attribute__( ( ext_vector_type( 4 ) ) );
 typedef __attribute__( ( address_space( 4 ) ) ) const v4u const_u4;         // constant address space:
 typedef __attribute__( ( address_space( 4 ) ) ) const uint32_t const_u32;   // loads at wave-uniform addresses are scalar loads
+typedef __attribute__( ( address_space( 4 ) ) ) const unsigned char const_u8;
+typedef v4u v4u_a8 __attribute__( ( aligned( 8 ) ) );
+typedef __attribute__( ( address_space( 4 ) ) ) const v4u_a8 const_u4_a8;
+typedef __attribute__( ( address_space( 4 ) ) ) const v2u const_u2;
 
 template <class IO>
 MRT_DEV void trace_packets( const DTrace& s, lds_u32* lds, const IO& io, uint32_t n, uint32_t* deal ) {
@@ -825,7 +884,7 @@ MRT_DEV void trace_packets( const DTrace& s, lds_u32* lds, const IO& io, uint32_
     stage_transforms( s, (lds_f32*)lds );
     const_u4* const cnodes  = (const_u4*)(uintptr_t)s.nodes;
     const_u32* const crefs  = (const_u32*)(uintptr_t)s.refs;
-    const_u4* const cprims  = (const_u4*)(uintptr_t)s.prims;
+    const_u8* const cprims  = (const_u8*)(uintptr_t)s.prims;
     const uint32_t lane     = __lane_id();
     const unsigned long long my_bit = 1ull << lane;
     uint32_t st_words[MRT_PACKET_STACK]; // deferred node e: lane 0 its reference, 1-2 the lanes that enter it, 3-4 those of them whose interval is restored, 5 its kind
@@ -953,7 +1012,9 @@ MRT_DEV void trace_packets( const DTrace& s, lds_u32* lds, const IO& io, uint32_
                 const uint32_t cnt = w1 >> 2;
                 for ( uint32_t k = 0; k < cnt; k++ ) {
                     const uint32_t obj = k == 0u ? r0 : crefs[w0 + k];
-                    const v4u q0 = cprims[obj * MRT_PRIM_Q], q1 = cprims[obj * MRT_PRIM_Q + 1u], q2 = cprims[obj * MRT_PRIM_Q + 2u];
+                    const uint32_t off = prim_offset( obj );
+                    const v4u q0 = *(const_u4_a8*)( cprims + off ), q1 = *(const_u4_a8*)( cprims + off + 16u );
+                    const v2u q2 = *(const_u2*)( cprims + off + 32u );
                     const uint32_t flags = q0.w, xf = flags >> MRT_PRIM_XF_SHIFT;
                     if ( xf != xr_id ) {
                         xro = o, xrd = d;
@@ -985,7 +1046,7 @@ MRT_DEV void trace_packets( const DTrace& s, lds_u32* lds, const IO& io, uint32_
             // ------------------------------------------------------------ retire
             if ( valid ) {
                 DHit h;
-                h.prim    = has ? (int32_t)( hprim & 0x7fffffffu ) : -1;
+                h.prim    = has ? (int32_t)prim_index( hprim & 0x7fffffffu ) : -1;
                 h.t       = has ? tmax : ray_tmax;
                 h.u       = has ? hu : 0.f;
                 h.v       = has ? hv : 0.f;

@@ -124,6 +124,7 @@ struct mrt_scene {
     DevBuf<uint4> nodes;
     DevBuf<uint32_t> refs;
     DevBuf<float4> prims;
+    DevBuf<uint2> prim_info;
     DevBuf<DXf> xforms;
     DevBuf<uint32_t> out_of_tree;
     DevBuf<uint32_t> object_of; // the caller's index of the object the library keeps at a given place (see mrt_scene_create)
@@ -335,24 +336,26 @@ mrt_status build_tree_records( const mrt_scene_desc* d, const std::vector<uint8_
                 if ( n_slots >= ( 1u << 27 ) ) break;
             }
         }
-        // a child as the traversal reads it: (w0, w1, first reference); `at`: where its list goes
+        // a child as the traversal reads it: (w0, w1, first reference); `at`: where its list goes.  References name a
+        // primitive by where its record lies (prim_loc)
         auto child = [&]( uint32_t n, uint32_t out[3], uint32_t& at ) {
             const uint32_t w0 = d->nodes[n].w0, w1 = d->nodes[n].w1;
             out[0] = w0, out[1] = w1, out[2] = 0;
             if ( ( w1 & 3u ) == 3u ) {
                 const uint32_t cnt = w1 >> 2;
-                if ( cnt > 0 ) out[2] = d->refs[w0];
+                if ( cnt > 0 ) out[2] = prim_loc( d->refs[w0] );
                 if ( inline_lists ) {
                     out[0] = cnt > 1 ? at - 1u : 0u;
                     uint32_t* pool = (uint32_t*)nodes.p;
                     for ( uint32_t k = 1; k < cnt; k++ )
-                        pool[at++] = d->refs[w0 + k];
+                        pool[at++] = prim_loc( d->refs[w0 + k] );
                 }
             }
             else out[1] = ( w1 & 3u ) | ( record[w1 >> 2] << 2 ); // its children are adjacent nodes of even depth: adjacent records
         };
         // the kernels form a slot's byte offset (slot << 5) in 32 bits
         if ( n_slots >= ( 1u << 27 ) ) return fail( MRT_ERR_UNSUPPORTED, "kd-tree too large (limit: 2^27 nodes of even depth, 4 GB of records and reference lists)" );
+        if ( inline_lists ) n_slots++; // the kernels fetch a list four references at a time: spare words behind the last list
         nodes = HostBuf<uint4>( 2 * (size_t)n_slots );
         if ( inline_lists ) std::memset( nodes.p, 0, 2 * (size_t)n_slots * sizeof( uint4 ) ); // the padding
         // every record (and its lists) is written by the one thread whose range holds its node
@@ -606,7 +609,10 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
 
     bool no_emitters = true;
     uint32_t kinds_seen = 0; // bit k: some object's material is of shade kind k
-    std::vector<float4> prims( MRT_PRIM_Q * (size_t)d->n_objects, make_float4( 0.f, 0.f, 0.f, 0.f ) );
+    // records of the traversal (layout in device_trace.hpp) and (flags, material) per object for shading
+    const size_t prim_bytes = (size_t)prim_offset( prim_loc( d->n_objects ? d->n_objects - 1u : 0u ) ) + 128u;
+    std::vector<float4> prims( prim_bytes / 16u, make_float4( 0.f, 0.f, 0.f, 0.f ) );
+    std::vector<uint2> prim_info( d->n_objects );
     for ( uint32_t i = 0; i < d->n_objects; i++ ) {
         uint32_t kind = d->obj_kind[i], mat = d->obj_material[i], xf = d->obj_transform[i];
         if ( mat >= d->n_materials ) return fail( MRT_ERR_INVALID, "object material out of range" );
@@ -626,15 +632,12 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
         kinds_seen |= 1u << shade_kind;
         uint32_t flags    = k | ( emissive ? MRT_PRIM_EMISSIVE : 0u ) | ( em_sum ? MRT_PRIM_EMISSIVE_SUM : 0u ) | ( shade_kind << MRT_PRIM_SHADE_SHIFT ) | ( xf << MRT_PRIM_XF_SHIFT );
         const float* p    = d->tri_p + 9 * (size_t)i;
-        float fl, fm;
-        std::memcpy( &fl, &flags, 4 );
-        std::memcpy( &fm, &mat, 4 );
         // e1 = p2 - p1, e2 = p3 - p1: one fp32 subtraction each, as triangle.cpp:9-10 does per test
-        float e1[3] = { p[3] - p[0], p[4] - p[1], p[5] - p[2] };
-        float e2[3] = { p[6] - p[0], p[7] - p[1], p[8] - p[2] };
-        prims[MRT_PRIM_Q * (size_t)i]     = make_float4( p[0], p[1], p[2], fl );
-        prims[MRT_PRIM_Q * (size_t)i + 1] = make_float4( e1[0], e1[1], e1[2], e2[0] );
-        prims[MRT_PRIM_Q * (size_t)i + 2] = make_float4( e2[1], e2[2], fm, 0.f );
+        const float rec[10] = { p[0], p[1], p[2], 0.f, p[3] - p[0], p[4] - p[1], p[5] - p[2], p[6] - p[0], p[7] - p[1], p[8] - p[2] };
+        char* at = (char*)prims.data() + prim_offset( prim_loc( i ) );
+        std::memcpy( at, rec, sizeof( rec ) );
+        std::memcpy( at + 12, &flags, 4 );
+        prim_info[i] = make_uint2( flags, mat );
     }
     std::vector<DXf> xforms( d->n_transforms );
     for ( uint32_t i = 0; i < d->n_transforms; i++ ) {
@@ -650,8 +653,18 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
     s->no_emitters = no_emitters;
     s->mixed_kinds = ( kinds_seen & ( kinds_seen - 1u ) ) != 0u;
     HIP_TRY( s->nodes.upload( nodes.p, nodes.n ) );
-    if ( !inline_lists ) HIP_TRY( s->refs.upload( d->refs, d->n_refs ) );
+    if ( !inline_lists ) {
+        parallel_ranges( d->n_refs, [&]( size_t begin, size_t end ) {
+            for ( size_t i = begin; i < end; i++ )
+                r_refs[i] = prim_loc( r_refs[i] );
+        } );
+        // (four spare words: the kernels fetch a list four references at a time)
+        HIP_TRY( s->refs.alloc( (size_t)d->n_refs + 4u ) );
+        HIP_TRY( hipMemset( s->refs.p, 0, ( (size_t)d->n_refs + 4u ) * sizeof( uint32_t ) ) );
+        if ( d->n_refs ) HIP_TRY( hipMemcpy( s->refs.p, r_refs.p, (size_t)d->n_refs * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
+    }
     HIP_TRY( s->prims.upload( prims ) );
+    HIP_TRY( s->prim_info.upload( prim_info ) );
     HIP_TRY( s->xforms.upload( xforms ) );
     HIP_TRY( s->out_of_tree.upload( d->out_of_tree, d->n_out_of_tree ) );
     HIP_TRY( s->object_of.upload( object_of ) );
@@ -694,6 +707,7 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
     t.nodes       = s->nodes.p;
     t.refs        = inline_lists ? (const uint32_t*)s->nodes.p : s->refs.p;
     t.prims       = s->prims.p;
+    t.prim_info   = s->prim_info.p;
     t.xforms      = s->xforms.p;
     t.out_of_tree = s->out_of_tree.p;
     t.n_nodes     = d->n_nodes;
