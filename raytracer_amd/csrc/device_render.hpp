@@ -268,6 +268,12 @@ struct CameraIO {
     }
     CameraRays rays() const { return CameraRays { pi, cam }; }
 };
+// camera rays: the samples of a pixel fetch the same records, which the first-level cache serves; the
+// kernel is bound by instruction issue and its registers are all in use, so no mailbox
+template <>
+struct Mailbox<CameraIO> {
+    static constexpr int size = 0;
+};
 template <bool STATS>
 __global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_camera_kernel( DTrace tr, CameraIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];

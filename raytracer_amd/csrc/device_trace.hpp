@@ -63,6 +63,18 @@ struct RefillMin {
     static constexpr uint32_t value = MRT_REFILL_MIN;
 };
 
+// Per ray source: how many primitives a ray remembers to have missed (see trace_stream); 0 = none.
+#ifndef MRT_MAILBOX
+#define MRT_MAILBOX 8
+#endif
+#ifndef MRT_MAILBOX_SKIPS
+#define MRT_MAILBOX_SKIPS 1
+#endif
+template <class IO>
+struct Mailbox {
+    static constexpr int size = MRT_MAILBOX;
+};
+
 // prim record: ten words, three records to a 128-byte line (slots at bytes 0, 40, 80; a record never
 // straddles two cache lines, and a line fetched for one primitive of a leaf brings two neighbours):
 //   words 0-3 = p1.xyz , flags      flags: bits 0-1 kind (0 triangle, 1 sphere, 2 plane),
@@ -117,6 +129,8 @@ struct DTrace {
     // runs on (7 on an unpartitioned MI355X; probed per device at scene creation, 0 = unknown
     // mapping or a single XCD)
     uint32_t xcd_mask;
+    // rays remember the triangles they were found to miss (trace_stream: mailbox); 0 for measurements and tests
+    uint32_t mailbox_on;
 };
 
 struct DHit {
@@ -212,7 +226,8 @@ MRT_DEV void transform_ray( const DTrace& s, const lds_f32* xf_lds, uint32_t xf,
 
 // Möller-Trumbore as shapes/triangle.cpp:4-40 evaluates it.  Returns true when the hit is accepted
 // into [tmin, tmax]; det is returned for the sidedness.
-MRT_DEV bool tri_test( V3 origin, V3 dir, float4 q0, float4 q1, float2 q2, float tmin, float tmax, float& t, float& u, float& v, float& det ) {
+// `apart` reports a miss that does not depend on [tmin, tmax]: the ray's line misses the triangle.
+MRT_DEV bool tri_test( V3 origin, V3 dir, float4 q0, float4 q1, float2 q2, float tmin, float tmax, float& t, float& u, float& v, float& det, bool& apart ) {
     // Evaluated without early exits: in a wave whose lanes test unrelated triangles some lane
     // always needs every term, and straight-line code spares the execution-mask bookkeeping of
     // four nested returns.  The accept condition is the reference's chain of rejections, each
@@ -230,7 +245,12 @@ MRT_DEV bool tri_test( V3 origin, V3 dir, float4 q0, float4 q1, float2 q2, float
     const bool u_out = ( u < 0.f ) | ( u > 1.f );
     const bool v_out = ( v < 0.f ) | ( u + v > 1.f );
     const bool t_in  = ( t >= tmin ) & ( t <= tmax );
-    return !flat & !u_out & !v_out & t_in;
+    apart = flat | u_out | v_out;
+    return !apart & t_in;
+}
+MRT_DEV bool tri_test( V3 origin, V3 dir, float4 q0, float4 q1, float2 q2, float tmin, float tmax, float& t, float& u, float& v, float& det ) {
+    bool apart;
+    return tri_test( origin, dir, q0, q1, q2, tmin, tmax, t, u, v, det, apart );
 }
 
 // Unit sphere in object space (shapes/sphere.cpp:52-133).  `wo`, `wd`: world ray (the one-root
@@ -310,6 +330,7 @@ MRT_DEV bool clip_root( const DTrace& s, V3 o, V3 d, float& ray_tmin, float& ray
 #define MRT_ST_IDLE 0u  // no ray
 #define MRT_ST_INNER 1u // node record in flight
 #define MRT_ST_TEST 3u  // record of the current primitive in flight
+#define MRT_NO_PRIM 0xffffffffu
 
 // Byte-offset loads: tables are addressed as base + 32-bit byte offset (checked at scene creation),
 // which the hardware forms from a scalar base and one vector register.
@@ -498,6 +519,27 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     // the references that follow in the current leaf's list, fetched four at a time: nq0 is the one at
     // position ptr when a record goes in flight, and the queue covers positions [ptr, qhi)
     uint32_t nq0 = 0, nq1 = 0, nq2 = 0, nq3 = 0, qhi = 0;
+    // Mailbox: the last MB triangles this ray's LINE was found to miss (tri_test: apart), newest first.
+    // A kd-tree references a triangle from every leaf it overlaps (here dozens), and half of the tests a
+    // ray makes are of a triangle it met a leaf or two earlier; a miss of that kind holds whatever the
+    // interval, so the record is not fetched again and the test not repeated: the reference's outcome
+    // (and its count of tests) without the look-ups.  obj == MRT_NO_PRIM: no record in flight this trip.
+    constexpr int MB = Mailbox<IO>::size;
+    static_assert( MB == 0 || MB == 4 || MB == 6 || MB == 8, "mailbox sizes: 0, 4, 6, 8" );
+    uint32_t mb[MB ? MB : 1];
+    auto mb_clear = [&]() {
+#pragma unroll
+        for ( int i = 0; i < MB; i++ )
+            mb[i] = 0xffffffffu;
+    };
+    auto mb_has = [&]( uint32_t id ) -> bool {
+        uint32_t x = 0xffffffffu;
+#pragma unroll
+        for ( int i = 0; i < MB; i++ )
+            x = min( x, id ^ mb[i] );
+        return x == 0u;
+    };
+    mb_clear();
     uint32_t cur  = 0; // the record in L0, L1
     uint32_t pick = 0; // after a pop: 2 = resume at the left child of the record, 3 = at the right one
     uint32_t xr_id = 0;    // transform of the object-space ray in LDS
@@ -562,6 +604,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                     trips = 0;
 #endif
                     xr_id    = 0;
+                    mb_clear();
                     if ( !BOOL_ONLY ) {
                         v2f m;
                         m.x = __uint_as_float( 0xffffffffu ), m.y = ray_tmax;
@@ -691,7 +734,10 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 st.leaves += at_leaf ? 1u : 0u;
             }
         }
-        if ( is_test ) {
+        const bool in_flight = is_test & ( MB == 0 || obj != MRT_NO_PRIM );
+        // (a lane in TEST without a record in flight was waiting for references only)
+        advance = advance | ( is_test & !in_flight );
+        if ( in_flight ) {
             if ( STATS ) {
                 st.refs++;
                 st.tests++;
@@ -708,8 +754,15 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             float t = 0.f, u = 0.f, v = 0.f, det = 0.f;
             bool outside = true, hit;
             if ( ( flags & 3u ) == MRT_PRIM_TRI ) {
-                hit     = tri_test( origin, dir, L0, L1, L2, a, tmax, t, u, v, det );
+                bool apart;
+                hit     = tri_test( origin, dir, L0, L1, L2, a, tmax, t, u, v, det, apart );
                 outside = !( det < 0.f );
+                if ( MB != 0 && apart ) {
+#pragma unroll
+                    for ( int i = MB - 1; i > 0; i-- )
+                        mb[i] = mb[i - 1];
+                    mb[0] = obj;
+                }
             }
             else { hit = sphere_test( s, xf_lds, xf, origin, dir, o, d, a, tmax, t, outside ); }
             // Accepted hits shrink the interval whether or not they are kept.  For a closest-hit ray
@@ -732,7 +785,28 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             advance              = !retire & !leaf_done;
             pop                  = !retire & leaf_done;
         }
-        state = ( advance & !is_test ) ? MRT_ST_TEST : state;
+        // the primitive the lane is about to fetch (nq0, at position ptr) and up to MRT_MAILBOX_SKIPS - 1
+        // after it are passed over when the ray is known to miss them
+        bool starve = false; // the leaf goes on, but its next reference has not been fetched yet
+        if ( MB != 0 ) {
+#pragma unroll
+            for ( int k = 0; k < MRT_MAILBOX_SKIPS; k++ ) {
+                const bool skip = advance & ( s.mailbox_on != 0u ) & mb_has( nq0 );
+                if ( STATS && skip ) {
+                    st.refs++;
+                    st.tests++;
+                }
+                ptr += skip ? 1u : 0u;
+                nq0 = skip ? nq1 : nq0, nq1 = skip ? nq2 : nq1, nq2 = skip ? nq3 : nq2;
+                const bool leaf_done = skip & ( ptr >= end );
+                const bool dry       = skip & !leaf_done & ( ptr >= qhi );
+                advance              = advance & !leaf_done & !dry;
+                retire               = retire | ( leaf_done & has );
+                pop                  = pop | ( leaf_done & !has );
+                starve               = starve | dry;
+            }
+        }
+        state = ( advance | starve ) ? MRT_ST_TEST : state;
         if ( TAIL && tail_trips > relay_after ) {
             // (wave-uniform branch, taken only in the tail of the launch) hand over the rays that have
             // just finished a leaf without a hit and have deferred nodes left: finite rays with no zero
@@ -812,10 +886,14 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             L1    = ld_prim( s, obj, 1 );
             L2    = ld_prim_tail( s, obj );
             nq0 = nq1, nq1 = nq2, nq2 = nq3;
-            if ( ptr + 1 >= qhi && ptr + 1 < end ) {
-                const v4u_a4 r = ld_ref4( s, ptr + 1 );
+        }
+        if ( MB != 0 && starve ) obj = MRT_NO_PRIM;
+        {
+            const uint32_t rpos = ptr + ( starve ? 0u : 1u ); // the position the queue must reach next
+            if ( ( advance | starve ) && rpos >= qhi && rpos < end ) {
+                const v4u_a4 r = ld_ref4( s, rpos );
                 nq0 = r.x, nq1 = r.y, nq2 = r.z, nq3 = r.w;
-                qhi = ptr + 5u;
+                qhi = rpos + 4u;
             }
         }
         if ( want_node ) {

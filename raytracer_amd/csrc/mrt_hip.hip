@@ -715,6 +715,11 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
     t.n_out       = d->n_out_of_tree;
     t.n_xforms    = d->n_transforms;
     {
+        // MRT_MAILBOX=0: every primitive of every visited leaf is fetched and tested (measurements and tests)
+        const char* e = std::getenv( "MRT_MAILBOX" );
+        t.mailbox_on  = e && std::strcmp( e, "0" ) == 0 ? 0u : 1u;
+    }
+    {
         mrt_status xs = xcd_mask_for_device( device, &t.xcd_mask );
         if ( xs != MRT_OK ) return xs;
     }

@@ -143,3 +143,39 @@ def test_camera_rays_as_packets_give_the_same_frame(built, monkeypatch, name):
         assert np.array_equal(_bits(x) if x.dtype == np.float32 else x, _bits(y) if y.dtype == np.float32 else y)
     dev.close()
     plain.close()
+
+
+@pytest.mark.parametrize("name", ["cornell", "bunny_plane", "veach", "transforms"])
+def test_the_mailbox_changes_nothing(built, monkeypatch, name):
+    """A ray remembers the last triangles its line was found to miss and passes them over, unfetched, in the
+    leaves that reference them again (trace_stream: mailbox).  With MRT_MAILBOX=0 every primitive of every
+    visited leaf is fetched and tested: hits, distances, barycentrics, the traversal counters (a triangle
+    passed over counts as tested, as the reference tests it) and frames are the same bits.  cornell's walls
+    are two triangles each that dozens of leaves reference and rays hit after leaves in which the same
+    triangle's distance lay outside the leaf's interval: those rejections must not be remembered."""
+    sc = _scene(name)
+    w, h = (96, 54) if name == "veach" else (96, 96)
+    flat = sc.initKdTree().flatten(1)
+    o, d, tmin, tmax = _rays(flat, 96, 96, 30000, 31)
+    out = []
+    for mode in (None, "0"):
+        if mode is None:
+            monkeypatch.delenv("MRT_MAILBOX", raising=False)
+        else:
+            monkeypatch.setenv("MRT_MAILBOX", mode)
+        dev = DeviceScene(flat)
+        res = []
+        for any_hit in (False, True):
+            assert _compare(flat, dev, o, d, tmin, tmax, any_hit) > 1000
+            r = dev.intersect(o, d, tmin, tmax, any_hit=any_hit, stats=True)
+            res.append(r[:4] + ((r[4].inner, r[4].leaves, r[4].refs, r[4].prim_tests),))
+        img = np.zeros((h, w, 3), np.float32)
+        rs = dev.render(render_params(w, h, 4, 4, max_depth=5, seed=9, paths_per_pass=w * h * 5), img)
+        out.append((res, img, rs.rays_closest, rs.rays_any))
+        dev.close()
+    for a, b in zip(out[0][0], out[1][0]):
+        assert a[4] == b[4]
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(_bits(x) if x.dtype == np.float32 else x, _bits(y) if y.dtype == np.float32 else y)
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][2:] == out[1][2:]
+    assert name == "transforms" or out[0][1].max() > 0  # (that scene has no light)
