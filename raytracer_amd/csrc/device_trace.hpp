@@ -578,6 +578,11 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         for ( int i = 0; i < MRT_EXTRA_VALU; i++ )
             asm volatile( "v_add_f32 %0, %0, %0" : "+v"( extra_valu ) );
 #endif
+#ifdef MRT_EXTRA_SALU
+#pragma unroll
+        for ( int i = 0; i < MRT_EXTRA_SALU; i++ )
+            asm volatile( "s_add_u32 s101, s101, 1" : : : "s101", "scc" ); // measurement aid: MRT_EXTRA_SALU more scalar-ALU instructions per trip
+#endif
         // ---------------------------------------------------------------- refill
         const unsigned long long idle = __ballot( state == MRT_ST_IDLE );
         const uint32_t n_idle         = (uint32_t)__popcll( idle );
@@ -696,7 +701,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             const bool near_only1 = ( t1 > b ) | ( t1 < 0.0f );
             const bool far_only1  = !near_only1 & ( t1 < a );
             const bool both1      = at_head & !near_only1 & !far_only1;
-            const bool right      = forced ? ( pick & 1u ) != 0u : ( lnear1 == far_only1 );
+            const bool right      = ( forced & ( ( pick & 1u ) != 0u ) ) | ( !forced & ( lnear1 == far_only1 ) ); // (no ?: -- it becomes a branch)
             if ( both1 ) push( cur | ( lnear1 ? 0xc0000000u : 0x80000000u ), b ); // far = right iff near = left
             b    = both1 ? t1 : b;
             pick = 0u;
@@ -737,7 +742,73 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         const bool in_flight = is_test & ( MB == 0 || obj != MRT_NO_PRIM );
         // (a lane in TEST without a record in flight was waiting for references only)
         advance = advance | ( is_test & !in_flight );
-        if ( in_flight ) {
+        if constexpr ( BOOL_ONLY )
+        {
+            // The primitive test of the occlusion kernels, computed in every lane, without a branch, and
+            // applied where a record is in flight.  Per-lane flags live in scalar masks, and a flag assigned
+            // under a divergent branch costs three scalar instructions to merge after it -- which this loop
+            // feels three times as much as vector instructions.  (The kernels that keep a hit record have no
+            // registers to spare for it: there the branch, which shortens live ranges, stays.)
+            bool hit = false, outside = true, is_tri = true;
+            float t = 0.f, u = 0.f, v = 0.f;
+            uint32_t flags = 0u;
+            {
+                if ( STATS && in_flight ) {
+                    st.refs++;
+                    st.tests++;
+                }
+                flags             = __float_as_uint( L0.w );
+                const uint32_t xf = flags >> MRT_PRIM_XF_SHIFT;
+                if ( in_flight & ( xf != xr_id ) ) {
+                    V3 oo = o, od = d;
+                    if ( xf != 0 ) transform_ray( s, xf_lds, xf, o, d, oo, od );
+                    put_xr( oo, od );
+                    xr_id = xf;
+                }
+                const V3 origin = xro, dir = xrd;
+                float det = 0.f;
+                bool apart;
+                is_tri             = ( flags & 3u ) == MRT_PRIM_TRI;
+                const bool hit_tri = tri_test( origin, dir, L0, L1, L2, a, tmax, t, u, v, det, apart );
+                uint32_t sph = 0u; // a sphere's outcome as bits of a vector register: 1 = hit, 2 = outside
+                if ( in_flight & !is_tri ) {
+                    float ts     = 0.f;
+                    bool outs    = true;
+                    const bool h = sphere_test( s, xf_lds, xf, origin, dir, o, d, a, tmax, ts, outs );
+                    sph          = ( h ? 1u : 0u ) | ( outs ? 2u : 0u );
+                    t            = ts;
+                }
+                hit     = in_flight & ( ( is_tri & hit_tri ) | ( ( sph & 1u ) != 0u ) );
+                outside = is_tri ? !( det < 0.f ) : ( sph & 2u ) != 0u;
+                if ( MB != 0 && ( in_flight & is_tri & apart ) ) {
+#pragma unroll
+                    for ( int i = MB - 1; i > 0; i-- )
+                        mb[i] = mb[i - 1];
+                    mb[0] = obj;
+                }
+            }
+            // Accepted hits shrink the interval whether or not they are kept.  For a closest-hit ray
+            // an accepted hit that is not kept has a distance that compares EQUAL to the kept one
+            // (t <= tmax and !(t < tmax)), so tmax stays the kept hit's own distance, which is what the
+            // reference reports (kdtree.cpp:547): the two differ when one is -0 and the other +0.
+            const bool keep = hit & ( ANY ? !( flags & MRT_PRIM_EMISSIVE ) : ( !has | ( t < tmax ) ) );
+            tmax            = ( ANY ? hit : keep ) ? t : tmax;
+            if ( !BOOL_ONLY && keep ) {
+                v2f m;
+                m.x = __uint_as_float( obj | ( outside ? 0x80000000u : 0u ) ), m.y = is_tri ? u : 0.f; // (a sphere reports no u, v)
+                *out_lds  = m;
+                *outv_lds = is_tri ? v : 0.f;
+            }
+            has = has | keep;
+            ptr += in_flight ? 1u : 0u;
+            // the search ends at the first leaf that produced a hit (a shadow ray: at the first hit)
+            const bool leaf_done = ptr >= end;
+            const bool ends      = ANY ? ( keep | ( leaf_done & has ) ) : ( leaf_done & has );
+            retire               = in_flight & ends;
+            advance              = advance | ( in_flight & !ends & !leaf_done );
+            pop                  = pop | ( in_flight & !ends & leaf_done );
+        }
+        else if ( in_flight ) {
             if ( STATS ) {
                 st.refs++;
                 st.tests++;
@@ -826,21 +897,20 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
                 }
             }
         }
-        if ( pop ) {
-            retire = sp == 0;
-            if ( sp != 0 ) {
-                --sp;
-                v2u e;
-                if ( sp < NST ) e = stack_lds[sp * MRT_TRACE_BLOCK];
-                else e = stack_deep[sp - NST];
-                a         = b;
-                b         = __uint_as_float( e.y );
-                node      = e.x & 0x3fffffffu;
-                pick      = e.x >> 30;
-                want_node = true;
-                state     = MRT_ST_INNER;
-            }
+        const bool do_pop = pop & ( sp != 0 );
+        retire            = retire | ( pop & ( sp == 0 ) );
+        if ( do_pop ) {
+            --sp;
+            v2u e;
+            if ( sp < NST ) e = stack_lds[sp * MRT_TRACE_BLOCK];
+            else e = stack_deep[sp - NST];
+            a    = b;
+            b    = __uint_as_float( e.y );
+            node = e.x & 0x3fffffffu;
+            pick = e.x >> 30;
         }
+        want_node = want_node | do_pop;
+        state     = do_pop ? MRT_ST_INNER : state;
         if ( retire ) {
             // a shadow ray that found an occluder in the tree never reaches the planes
             if ( STATS && !( ANY && has ) ) st.tests += pl_tests;
