@@ -275,7 +275,10 @@ struct Mailbox<CameraIO> {
     static constexpr int size = 0;
 };
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) extend_camera_kernel( DTrace tr, CameraIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
+#ifndef MRT_CAMERA_WAVES
+#define MRT_CAMERA_WAVES MRT_TRACE_WAVES
+#endif
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_CAMERA_WAVES ) extend_camera_kernel( DTrace tr, CameraIO io, uint32_t n, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( false )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
