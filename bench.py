@@ -307,12 +307,16 @@ def measure(name, args, rank, world, dist, local_rank, with_cpu):
                         "kernels themselves on an untimed pass) of the kernel's launches of one step / their summed HIP-event time.  "
                         "traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch from the committed counter passes (profiles/hbm_traffic.json; "
                         "the doubling is calibrated for this access pattern, profiles/r03_gather_calibration.json); "
-                        "hbm_frac_from_counters = traffic / launch time / peak.  The traversal gathers 16 bytes at a time and every gather "
-                        "that misses the L2 moves a whole 128-byte line, so what bounds the kernel is the number of lines the fabric "
-                        "delivers per second, not their bytes: line_fetch."}
+                        "hbm_frac_from_counters = traffic / launch time / peak.  prim_tests counts what the reference tests; the kernels "
+                        "pass over the triangles a ray is known to miss (mailbox) without fetching them, so fewer bytes than these move.  "
+                        "The traversal gathers 16 bytes at a time and every gather that misses the L2 moves a whole 128-byte line: "
+                        "line_fetch prices the lines against what the fabric delivers to a loop that does nothing else."}
         if traffic and launches:
             roof["hbm_frac_from_counters"] = traffic / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS
-            roof["limiter"] = "fabric line fetches: one 128-byte line per L2 miss of a 16-byte gather" + (" (TCC hit rate %.2f)" % hit_rate if hit_rate else "")
+            roof["limiter"] = ("cache look-ups and scalar instructions per trip of the traversal loop, not bytes or lines: with the loop unchanged, 22 % "
+                               "fewer fabric line fetches (leaf lists next to their tree records, three primitive records a line) bought 3.5 %; one "
+                               "look-up per four leaf references instead of one per reference bought 7 %; 16 more scalar instructions per trip cost "
+                               "2 %, 32 more vector instructions 1 %" + (" (TCC hit rate %.2f)" % hit_rate if hit_rate else ""))
         if miss_lines and launches:
             rate = miss_lines / (ms / launches * 1e-3) / 1e9
             roof["line_fetch"] = {"lines_per_launch": miss_lines, "G_lines_per_s": rate, "ceiling_G_lines_per_s": line_ceiling,

@@ -436,8 +436,8 @@ def test_object_order_inside_the_library_is_invisible(built, monkeypatch):
 @pytest.mark.parametrize("name", ["cornell", "bunny_plane", "transforms", "fuzz3", "fuzz6"])
 def test_where_the_leaf_lists_live_is_invisible(built, monkeypatch, name):
     """The leaves' reference lists inside the pool of tree records right behind the pair of records that
-    holds them (the default), the same with groups that fit a cache line kept from straddling two
-    (MRT_REFS_INLINE=2), or in an array of their own (=0): hits equal the oracle's, every output array
+    holds them, groups that fit a cache line kept from straddling two (the default), the same packed without
+    regard to lines (MRT_REFS_INLINE=1), or in an array of their own (=0): hits equal the oracle's, every output array
     and the traversal counters are the same bits in all three, both node layouts, packets included."""
     from tests import fuzz_scenes
     if name == "cornell":
@@ -453,7 +453,7 @@ def test_where_the_leaf_lists_live_is_invisible(built, monkeypatch, name):
         flat = tree.flatten(layout)
         o, d, tmin, tmax = _rays(flat, 96, 96, 20000, 5)
         out = []
-        for mode in (None, "0", "2"):
+        for mode in (None, "0", "1"):
             if mode is None:
                 monkeypatch.delenv("MRT_REFS_INLINE", raising=False)
             else:
