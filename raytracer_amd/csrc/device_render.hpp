@@ -601,7 +601,7 @@ struct ShadowIO {
 };
 
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_OCCLUSION_WAVES ) connect_shadow_kernel( DTrace tr, ShadowIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( true )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };
@@ -675,7 +675,7 @@ struct RefillMin<MisOcclusionIO> {
 #endif
 
 template <bool STATS>
-__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_TRACE_WAVES ) connect_mis_occlusion_kernel( DTrace tr, MisOcclusionIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
+__global__ void __launch_bounds__( MRT_TRACE_BLOCK, MRT_OCCLUSION_WAVES ) connect_mis_occlusion_kernel( DTrace tr, MisOcclusionIO io, const uint32_t* __restrict__ count, uint32_t* __restrict__ deal, unsigned long long* __restrict__ stats, Relay relay ) {
     __shared__ uint32_t lds[MRT_TRACE_LDS_WORDS( true )];
     lds_u32* lp = (lds_u32*)lds;
     DStats st { 0, 0, 0, 0 };

@@ -176,6 +176,10 @@ __device__ unsigned long long g_trip_hist[32];
 #ifndef MRT_TOP_LDS
 #define MRT_TOP_LDS 0
 #endif
+// waves per SIMD the occlusion-only kernels (which keep no hit record and fewer registers) are compiled for
+#ifndef MRT_OCCLUSION_WAVES
+#define MRT_OCCLUSION_WAVES MRT_TRACE_WAVES
+#endif
 #define MRT_TRACE_LDS_WORDS( BOOL_ONLY ) \
     ( MRT_XF_LDS * 12 + MRT_TOP_LDS * 8 + ( ( BOOL_ONLY ) ? MRT_STACK_LDS_BOOL * MRT_TRACE_BLOCK * 2 : MRT_STACK_LDS * MRT_TRACE_BLOCK * 2 + MRT_TRACE_BLOCK * 7 ) )
 
@@ -525,7 +529,7 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
     // interval, so the record is not fetched again and the test not repeated: the reference's outcome
     // (and its count of tests) without the look-ups.  obj == MRT_NO_PRIM: no record in flight this trip.
     constexpr int MB = Mailbox<IO>::size;
-    static_assert( MB == 0 || MB == 4 || MB == 6 || MB == 8, "mailbox sizes: 0, 4, 6, 8" );
+    static_assert( MB >= 0 && MB <= 16, "mailbox sizes: 0 .. 16" );
     uint32_t mb[MB ? MB : 1];
     auto mb_clear = [&]() {
 #pragma unroll
@@ -742,7 +746,13 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
         const bool in_flight = is_test & ( MB == 0 || obj != MRT_NO_PRIM );
         // (a lane in TEST without a record in flight was waiting for references only)
         advance = advance | ( is_test & !in_flight );
-        if constexpr ( BOOL_ONLY )
+#ifndef MRT_TEST_EVERY_LANE
+#define MRT_TEST_EVERY_LANE 0 // 1: also in the kernels that keep a hit record (they need more than 80 registers for it)
+#endif
+#ifndef MRT_TEST_EVERY_LANE_OCCLUSION
+#define MRT_TEST_EVERY_LANE_OCCLUSION 1
+#endif
+        if constexpr ( ( BOOL_ONLY && MRT_TEST_EVERY_LANE_OCCLUSION ) || MRT_TEST_EVERY_LANE )
         {
             // The primitive test of the occlusion kernels, computed in every lane, without a branch, and
             // applied where a record is in flight.  Per-lane flags live in scalar masks, and a flag assigned
