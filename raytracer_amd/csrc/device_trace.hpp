@@ -34,6 +34,10 @@
 // states are mixed; lanes whose ray retired are refilled from the wave's current chunk once enough
 // of them are idle.  Rays differ in length by orders of magnitude, so without the refill a wave runs
 // at the pace of its longest ray with most lanes idle.
+// What a trip costs, measured: the first-level cache look-ups its lanes make (a divergent load is one
+// look-up per lane) and its scalar instructions (three times as dear as vector instructions: masks of
+// per-lane flags, branch bookkeeping) -- hence leaf references fetched four to a load, the mailbox of
+// triangles a ray is known to miss, and flags that are not assigned under divergent branches.
 //
 // The deferred-node stack stores (node, tmax) only: the entry interval of a popped node is always
 // the exit value b of the leaf visited just before it (the same float, carried by assignment),
