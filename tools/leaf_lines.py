@@ -1,6 +1,6 @@
-"""How many 128-byte lines a leaf's primitives span: with the records in first-reference order and an
-index list per leaf (the layout in use), against a copy of every record per reference, contiguous per
-leaf.  Leaves are weighted by the surface area of their boxes (the chance that a random ray visits them).
+"""How many 128-byte lines a leaf's primitives span: with 64-byte records in first-reference order and an
+index list per leaf in an array of its own (the layout this tool was written to question), against a copy
+of every record per reference, contiguous per leaf.  Leaves are weighted by the surface area of their boxes (the chance that a random ray visits them).
 
 usage: python tools/leaf_lines.py [scene] [width height]
 """
@@ -38,7 +38,7 @@ def main():
     print("  area-weighted mean %.2f (plain mean %.2f)" % ((w * cnt).sum(), cnt.mean()))
     cur_prim = np.zeros(len(cnt)); cur_ref = np.zeros(len(cnt)); dup = np.zeros(len(cnt)); dup48 = np.zeros(len(cnt))
     pos = 0  # position of the leaf's first copy in the per-reference array
-    for i, (o, c) in enumerate(zip(off, cnt)):
+    for i, (o, c) in enumerate(zip(off.tolist(), cnt.tolist())):
         if c:
             r = refs[o:o + c]
             cur_prim[i] = len(np.unique(new_index[r] >> 1))
@@ -47,7 +47,7 @@ def main():
             dup48[i] = (((pos + c) * 48 - 1) >> 7) - ((pos * 48) >> 7) + 1
             pos += c
     print("lines per leaf visit, area-weighted, if every primitive of a visited leaf is tested and nothing is cached:")
-    print("  in use (64-B records in first-reference order + index list): records %.2f + list %.2f = %.2f" % (
+    print("  64-B records in first-reference order + index list in its own array: records %.2f + list %.2f = %.2f" % (
         (w * cur_prim).sum(), (w * cur_ref).sum(), (w * (cur_prim + cur_ref)).sum()))
     print("  a 64-B copy per reference, contiguous per leaf: %.2f   (%.0f MB instead of %.0f MB)" % (
         (w * dup).sum(), len(refs) * 64 / 1e6, (n_obj * 64 + len(refs) * 4) / 1e6))
