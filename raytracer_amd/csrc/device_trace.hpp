@@ -377,10 +377,11 @@ MRT_HD uint32_t prim_offset( uint32_t loc ) { // in bytes
     return loc << 6;
 #endif
 }
-typedef float4 float4_a8 __attribute__( ( aligned( 8 ) ) );
+typedef float v4f_a8 __attribute__( ( ext_vector_type( 4 ), aligned( 8 ) ) ); // (a record's slots are 8-byte aligned)
 // the first two quarters of a record (k = 0, 1) and its last two words
 MRT_DEV float4 ld_prim( const DTrace& s, uint32_t loc, uint32_t k ) {
-    return *(const float4_a8*)( (const char*)s.prims + ( prim_offset( loc ) + k * 16u ) );
+    const v4f_a8 r = *(const v4f_a8*)( (const char*)s.prims + ( prim_offset( loc ) + k * 16u ) );
+    return make_float4( r.x, r.y, r.z, r.w );
 }
 MRT_DEV float2 ld_prim_tail( const DTrace& s, uint32_t loc ) {
     return *(const float2*)( (const char*)s.prims + ( prim_offset( loc ) + 32u ) );
