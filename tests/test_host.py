@@ -557,9 +557,14 @@ def test_host_library_under_address_and_ub_sanitizers(built):
     exe = build.build_sanitize()
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
                LSAN_OPTIONS="suppressions=" + os.path.join(ROOT, "tests", "sanitize", "lsan.supp") + ":print_suppressions=0")
-    r = subprocess.run([exe, os.path.join(ROOT, "assets")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and "host_sanitize ok" in r.stdout, r.stdout[-3000:]
-    assert "ERROR: AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout and "LeakSanitizer" not in r.stdout, r.stdout[-3000:]
+    # the three placements of the leaves' reference lists mrt_scene_create can build (in the pool of tree
+    # records, line-aligned: the default; the same unaligned; in an array of their own)
+    for lists in (None, "1", "0"):
+        if lists is not None:
+            env["MRT_REFS_INLINE"] = lists
+        r = subprocess.run([exe, os.path.join(ROOT, "assets")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "host_sanitize ok" in r.stdout, r.stdout[-3000:]
+        assert "ERROR: AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout and "LeakSanitizer" not in r.stdout, r.stdout[-3000:]
 
 
 def _png_decode(path):
