@@ -244,6 +244,9 @@ typedef struct mrt_render_stats {
  * order inside a leaf's list, which decides ties, is the caller's, and every object index that
  * leaves the library (mrt_hits.prim) is the caller's.  MRT_OBJECT_ORDER=input in the environment
  * keeps the caller's order (measurements only).
+ * Size limits (MRT_ERR_UNSUPPORTED beyond): fewer than 2^26 objects and transforms, 2^28 tree nodes,
+ * 2^30 leaf references, tree depth at most 126, and tree records plus leaf lists below 4 GB (about
+ * 60 M nodes with 150 M references).
  * Every index the description carries is checked on the host before the device is touched (tree
  * children and leaf ranges, one parent per node, depth; leaf references; out-of-tree planes; object
  * material / transform / kind; material type and texture; texture kind and texel window; light
