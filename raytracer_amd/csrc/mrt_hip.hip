@@ -583,10 +583,10 @@ static mrt_status scene_create( const mrt_scene_desc* d, int device, mrt_scene**
 
     // MRT_REFS_INLINE=0 keeps the leaves' reference lists in an array of their own, =1 packs the groups of records and lists
     // without regard to cache lines (measurements and tests)
+    const char* inl = std::getenv( "MRT_REFS_INLINE" );
 #if MRT_TOP_LDS
     const bool inline_lists = false; // (the staged top of the tree is addressed by record number)
 #else
-    const char* inl         = std::getenv( "MRT_REFS_INLINE" );
     const bool inline_lists = !( inl && std::strcmp( inl, "0" ) == 0 );
 #endif
     const bool align_groups = inline_lists && !( inl && std::strcmp( inl, "1" ) == 0 ); // MRT_REFS_INLINE=1: groups packed without regard to cache lines
