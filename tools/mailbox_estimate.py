@@ -72,6 +72,7 @@ def main():
     tests = distinct = leaves = 0
     caught = {1: 0, 2: 0, 4: 0, 8: 0}
     caught_prev_leaf = 0
+    pol = {"lru": 0, "again": 0}
     for i in range(len(o1)):
         with np.errstate(divide="ignore", invalid="ignore"):
             ta, tb = (bmin - o1[i]) / w[i], (bmax - o1[i]) / w[i]
@@ -100,6 +101,20 @@ def main():
                     box.append(x)
                     if len(box) > nmb:
                         box.pop(0)
+        # policies of an 8-entry memory: true LRU, and first-in first-out where a caught primitive is entered again
+        lru, dup = [], []
+        for x in seq:
+            if x in lru:
+                pol["lru"] += 1
+                lru.remove(x)
+            lru.append(x)
+            if len(lru) > 8:
+                lru.pop(0)
+            if x in dup:
+                pol["again"] += 1
+            dup.append(x)
+            if len(dup) > 8:
+                dup.pop(0)
         prev = set()
         for l in lists:
             caught_prev_leaf += sum(1 for x in l if x in prev)
@@ -110,6 +125,8 @@ def main():
     print("  distinct lines of primitive records per ray: %.2f at two records a line (in use), %.2f at three, %.2f at four" % (lines2 / n, lines3 / n, lines4 / n))
     for nmb, c in caught.items():
         print("  a memory of the last %d distinct primitives catches %.1f %% of the tests" % (nmb, 100 * c / tests))
+    print("  8 entries, least recently used replaced: %.1f %%; first-in first-out with caught primitives entered again: %.1f %%" % (
+        100 * pol["lru"] / tests, 100 * pol["again"] / tests))
     print("  'was in the leaf before' catches %.1f %%" % (100 * caught_prev_leaf / tests))
 
 
