@@ -1,7 +1,8 @@
 """Differential run of mrt_intersect against the oracle on the seeded random scenes of
 tests/fuzz_scenes.py; prints every mismatch.  usage: fuzz_debug.py first_seed n_seeds"""
 import sys
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from raytracer_amd.host import DeviceScene
 from tests import orc, fuzz_scenes
@@ -21,6 +22,13 @@ for seed in range(first, first + count):
         want, ws = orc.oracle_intersect(flat.desc, o, d, tmin, tmax, any_hit, stats=True)
         prim, t, u, v, gs = dev.intersect(o, d, tmin, tmax, any_hit=any_hit, stats=True)
         hit = want["prim"] >= 0
+        # the kernels without counters are other instantiations of the same loop: same four arrays
+        plain = dev.intersect(o, d, tmin, tmax, any_hit=any_hit)
+        for x, y in zip(plain, (prim, t, u, v)):
+            if not np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y):
+                total += 1
+                print("seed", seed, "any_hit", any_hit, "the kernels with and without counters differ")
+                break
         bad = np.nonzero(((prim >= 0) != hit) | (hit & ((t.view(np.uint32) != want["t"].view(np.uint32)) | (prim != want["prim"]))))[0]
         stats_ok = (gs.inner, gs.leaves, gs.refs, gs.prim_tests) == (ws.inner, ws.leaves, ws.refs, ws.prim_tests)
         total += len(bad) + (0 if stats_ok else 1)

@@ -1,7 +1,8 @@
 """mrt_render against the oracle's path tracer (same counter-based samples) on the random shaded
 scenes of tests/fuzz_scenes.py.  usage: fuzz_render.py first_seed n_seeds [min_roughness [rich]]"""
 import sys
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from raytracer_amd.host import DeviceScene, render_params
 from tests import orc, fuzz_scenes
