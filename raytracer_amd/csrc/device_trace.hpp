@@ -913,6 +913,13 @@ MRT_DEV void trace_stream( const DTrace& s, lds_u32* lds, const IO& io, uint32_t
             }
         }
         const bool do_pop = pop & ( sp != 0 );
+#ifdef MRT_COUNT_DEEP_POPS
+        // measurement aid (with MRT_TRIP_HISTOGRAM): bucket 28 counts the trips of all waves, 29 those in which some
+        // lane takes a deferred node back from the scratch part of its stack, 30 those with a push into it
+        if ( __lane_id() == 0 ) atomicAdd( &g_trip_hist[28], 1ull );
+        if ( __ballot( do_pop && sp > NST ) != 0ull && __lane_id() == 0 ) atomicAdd( &g_trip_hist[29], 1ull );
+        if ( __ballot( sp > NST ) != 0ull && __lane_id() == 0 ) atomicAdd( &g_trip_hist[30], 1ull );
+#endif
         retire            = retire | ( pop & ( sp == 0 ) );
         if ( do_pop ) {
             --sp;
