@@ -2,7 +2,8 @@
 (mrt_render_multi: the samples divided between two concurrent pipelines).  usage: two_handles_bench.py [scene] [spp_x spp_y]"""
 import sys
 import time
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import scenes
 
 name = sys.argv[1] if len(sys.argv) > 1 else "million_bunny"
